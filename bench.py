@@ -1,0 +1,208 @@
+#!/usr/bin/env python
+"""Headline benchmark: frames/s of the 256x256 MPII pose forward (BASELINE.json configs[1]).
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+One "step" = one forward pass of ReceptionNet (8 blocks, J=16, 2 contexts, 5x5) over one batch of 64
+synthetic 256x256x3 frames per GPU, inputs already resident in HBM, all outputs (8 x [pose, visible]) left in
+HBM.  Frames shard embarrassingly over ranks (weak scaling, no data-path collective for the pose-only path);
+value = frames all ranks processed / max-over-ranks wall time of exactly K steps bracketed by barriers +
+device synchronisation.  Rank 0 prints ONE JSON line, which also carries
+  roofline     : the dominant kernel (MFMA implicit-GEMM conv) -- algorithmic FLOPs of all its launches in one
+                 step / their summed duration, measured with HIP events recorded on the launch stream in a
+                 separate eager pass right after the timed region (kernels inside a replayed hipGraph cannot
+                 be bracketed by events); peak = 157.3 TFLOP/s fp32 MFMA (MI355X_MICROARCH.md).
+  cpu_baseline : the CPU oracle (a port; TensorFlow/Keras are not installable here) timed on the host cores
+                 of this box on a bounded sample of the same workload.  N=1, rank 0 only.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+PEAK_FP32_MFMA_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md "Peak FP32 (matrix)"
+PEAK_HBM_GBS = 8000.0
+
+
+def build_model(blocks):
+    from deephar_amd import graph, weights
+    from deephar_amd.models import reception
+    graph.reset_naming()
+    m = reception.build((256, 256, 3), 16, dim=2, num_blocks=blocks, num_context_per_joint=2, ksize=(5, 5),
+                        concat_pose_confidence=False)
+    weights.init_synthetic(m, seed=0)
+    return m
+
+
+def cpu_baseline(model, blocks, budget_s=12.0):
+    """Oracle (torch-CPU fp32) frames/s on all host cores; bounded to ~budget_s of CPU work."""
+    import torch
+    from deephar_amd import weights
+    from oracle import reception as oref
+    from oracle.naming import Weights
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    wd = Weights(weights.as_dict(model))
+    bs = 8
+    x = np.random.default_rng(0).uniform(-1, 1, (bs, 256, 256, 3)).astype(np.float32)
+    kw = dict(num_context_per_joint=2, num_blocks=blocks, ksize=(5, 5), concat_pose_confidence=False)
+    oref.forward(wd, x, 16, 2, **kw)  # warm-up
+    t0 = time.perf_counter()
+    frames = 0
+    while True:
+        oref.forward(wd, x, 16, 2, **kw)
+        frames += bs
+        dt = time.perf_counter() - t0
+        if dt >= budget_s or frames >= 256:
+            break
+    return dict(value=round(frames / dt, 2), unit='frames/s', cores=cores, kind='port',
+                sample='%d frames (batches of %d) of the same 256x256x3 workload through oracle/reception.py '
+                       '(PyTorch-CPU fp32, %d threads), %.1f s' % (frames, bs, cores, dt))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--batch', type=int, default=64, help='frames per GPU per step (BASELINE cfg 2: 64)')
+    ap.add_argument('--blocks', type=int, default=8)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-graph', action='store_true', help='launch kernels eagerly instead of hipGraph replay')
+    ap.add_argument('--dump-steps', default=None, help='write the per-kernel profile (JSON) to this path')
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit('--gpus %d needs torch.distributed.run with --nproc-per-node %d' % (args.gpus, args.gpus))
+    if not torch.cuda.is_available():
+        raise SystemExit('bench.py needs a HIP device (the product path has no CPU fallback)')
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', rank=rank, world_size=world,
+                                device_id=torch.device('cuda', local_rank))
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    model = build_model(args.blocks)
+    plan = model.plan
+    ex = model.executor
+    ex.use_graph = not args.no_graph
+    n = args.batch
+    bp = ex.bind(n)
+    x = np.random.default_rng(1234 + rank).uniform(-1, 1, (n, 256, 256, 3)).astype(np.float32)
+    with torch.cuda.stream(ex.stream):
+        ex.set_inputs(bp, [x])           # inputs resident in HBM before the timed region
+    ex.stream.synchronize()
+
+    def step():
+        # the input buffer is re-used by later activations inside one forward, so every step re-stages the
+        # frames from a second HBM-resident copy (device-to-device, inside the timed region)
+        with torch.cuda.stream(ex.stream):
+            bp.tensor(plan.inputs[0]).copy_(x_dev, non_blocking=True)
+            ex.forward(bp)
+
+    with torch.cuda.stream(ex.stream):
+        x_dev = torch.from_numpy(x).to(ex.device)
+    ex.stream.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    ex.stream.synchronize()
+    torch.cuda.synchronize()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    ex.stream.synchronize()
+    torch.cuda.synchronize()
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device='cuda')
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    # sanity: outputs finite and in range
+    pose = bp.tensor(plan.outputs[-2]).cpu().numpy()
+    ok = bool(np.all(np.isfinite(pose)) and pose.min() >= 0 and pose.max() <= 1)
+
+    # ---- per-kernel pass (HIP events on the launch stream) ----------------------------------------------
+    with torch.cuda.stream(ex.stream):
+        bp.tensor(plan.inputs[0]).copy_(x_dev)
+        times_ms = bp.profile(ex.stream_ptr, reps=3)
+    kinds = {}
+    for s, ms in zip(plan.steps, times_ms):
+        k = kinds.setdefault(s.kind, dict(ms=0.0, flops=0.0, bytes=0.0, launches=0))
+        k['ms'] += float(ms)
+        k['flops'] += s.flops(n)
+        k['bytes'] += s.bytes(n)
+        k['launches'] += 1
+    conv = kinds['conv']
+    achieved = conv['flops'] / (conv['ms'] * 1e-3) / 1e12
+    eager_total_ms = float(np.sum(times_ms))
+
+    if rank == 0:
+        value = world * n * args.steps / dt
+        out = {
+            'metric': 'frames/sec whole-node, 256x256 MPII pose fwd',
+            'value': round(value, 1),
+            'unit': 'frames/s',
+            'n_gpus': world,
+            'steps': args.steps,
+            'warmup': args.warmup,
+            'ms_per_step': round(1e3 * dt / args.steps, 3),
+            'higher_is_better': True,
+            'scaling': 'weak',
+            'vs_baseline': None,
+            'dtype': 'f32',
+            'data': 'synthetic',
+            'config': {'workload': 'MPII single-person 256x256, ReceptionNet %d blocks J=16 ctx=2 k=5, pose-only '
+                                   'forward, batch=%d per GPU (BASELINE.json configs[1])' % (args.blocks, n),
+                       'global_batch': world * n, 'parallelism': 'frame-shard x%d (no collective)' % world,
+                       'hipgraph': not args.no_graph, 'outputs_finite_in_range': ok},
+            'roofline': {'bound': 'mfma', 'kernel': 'conv_igemm_kernel (all %d launches of one step)' % conv['launches'],
+                         'achieved': round(achieved, 2), 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
+                         'frac': round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), 'traffic': None,
+                         'avg_launch_us': round(1e3 * conv['ms'] / conv['launches'], 2),
+                         'gflop_per_step': round(conv['flops'] / 1e9, 2),
+                         'whole_forward_frac': round(plan.total_flops(n) * args.steps / dt / 1e12 /
+                                                     PEAK_FP32_MFMA_TFLOPS, 4)},
+            'kernel_time_share': {k: round(v['ms'] / eager_total_ms, 4) for k, v in sorted(kinds.items())},
+            'hbm_bound_kernels': {k: {'GBps': round(v['bytes'] / (v['ms'] * 1e-3) / 1e9, 1),
+                                      'frac_of_8TBps': round(v['bytes'] / (v['ms'] * 1e-3) / 1e9 / PEAK_HBM_GBS, 4)}
+                                  for k, v in sorted(kinds.items()) if k in ('dwconv', 'pool', 'sam') and v['ms'] > 0},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out['cpu_baseline'] = cpu_baseline(model, args.blocks)
+        if args.dump_steps:
+            rows = [dict(kind=s.kind, name=s.name, ms=float(ms), gflop=s.flops(n) / 1e9, mbytes=s.bytes(n) / 1e6,
+                         out=list(next(iter(s.outs.values())).shape) if s.outs else None)
+                    for s, ms in zip(plan.steps, times_ms)]
+            with open(args.dump_steps, 'w') as f:
+                json.dump(rows, f, indent=1)
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

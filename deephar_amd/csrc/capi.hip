@@ -1,0 +1,184 @@
+// extern "C" surface of libdeephar_hip.so (see include/deephar_hip.h for the contract and the
+// reference interfaces each entry point replaces).  Thin: validate, forward to the launcher.
+#include <string.h>
+#include <vector>
+#include "dh_kernels.h"
+
+using namespace dh;
+
+static inline hipStream_t S(void* s) { return reinterpret_cast<hipStream_t>(s); }
+static inline int rc_of(hipError_t e) { return e == hipSuccess ? DH_OK : DH_ELAUNCH; }
+
+extern "C" {
+
+int dh_version(void) { return 100; }
+
+const char* dh_error_string(int rc) {
+  switch (rc) {
+    case DH_OK: return "ok";
+    case DH_EINVAL: return "invalid argument or shape";
+    case DH_EUNSUPPORTED: return "configuration not supported by the gfx950 kernels";
+    case DH_ELAUNCH: return "HIP launch/runtime error";
+    default: return "unknown error";
+  }
+}
+
+int dh_device_info(int dev, char* arch_name, int arch_name_len, int* cu_count) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || dev < 0 || dev >= n) return DH_ELAUNCH;
+  hipDeviceProp_t p;
+  if (hipGetDeviceProperties(&p, dev) != hipSuccess) return DH_ELAUNCH;
+  if (arch_name != nullptr && arch_name_len > 0) {
+    strncpy(arch_name, p.gcnArchName, (size_t)arch_name_len - 1);
+    arch_name[arch_name_len - 1] = 0;
+  }
+  if (cu_count != nullptr) *cu_count = p.multiProcessorCount;
+  return DH_OK;
+}
+
+int dh_conv2d_packed_dims(int KH, int KW, int Cin, int Cout, int* Kp, int* Np) {
+  if (KH <= 0 || KW <= 0 || Cin <= 0 || Cout <= 0) return DH_EINVAL;
+  const int K = KH * KW * Cin;
+  if (Kp != nullptr) *Kp = (K + 31) / 32 * 32;
+  if (Np != nullptr) *Np = (Cout + 31) / 32 * 32;
+  return DH_OK;
+}
+
+int dh_conv2d_pack_weights_host(const float* w, float* packed, int KH, int KW, int Cin, int Cout) {
+  int Kp, Np;
+  if (w == nullptr || packed == nullptr || dh_conv2d_packed_dims(KH, KW, Cin, Cout, &Kp, &Np) != DH_OK)
+    return DH_EINVAL;
+  const int K = KH * KW * Cin;
+  memset(packed, 0, sizeof(float) * (size_t)Kp * Np);
+  // HWIO flattened k = (kh*KW + kw)*Cin + ci ; packed[(k/4)*Np*4 + n*4 + k%4]
+  for (int k = 0; k < K; ++k)
+    for (int n = 0; n < Cout; ++n)
+      packed[((size_t)(k >> 2) * Np + n) * 4 + (k & 3)] = w[(size_t)k * Cout + n];
+  return DH_OK;
+}
+
+int dh_conv2d_num_tile_cfgs(void) { return conv_igemm_num_cfgs(); }
+int dh_conv2d_pick_tile_cfg(int M, int Cout) { return conv_igemm_pick_cfg(M, Cout); }
+
+int dh_conv2d_f32(const dh_conv_args* a, int tile_cfg, void* stream) {
+  if (a == nullptr || a->x == nullptr || a->w == nullptr || a->y == nullptr) return DH_EINVAL;
+  if ((a->pre_scale == nullptr) != (a->pre_shift == nullptr)) return DH_EINVAL;
+  if ((a->post_scale == nullptr) != (a->post_shift == nullptr)) return DH_EINVAL;
+  if (a->SH <= 0 || a->SW <= 0 || a->KH <= 0 || a->KW <= 0) return DH_EINVAL;
+  return launch_conv_igemm(*a, tile_cfg, S(stream));
+}
+
+int dh_dwconv2d_f32(const dh_dw_args* a, void* stream) {
+  if (a == nullptr || a->x == nullptr || a->w == nullptr || a->y == nullptr) return DH_EINVAL;
+  if ((a->pre_scale == nullptr) != (a->pre_shift == nullptr)) return DH_EINVAL;
+  return launch_dwconv(*a, S(stream));
+}
+
+int dh_pool2d_f32(const dh_pool_args* a, void* stream) {
+  if (a == nullptr || a->x == nullptr || a->y == nullptr || a->SH <= 0 || a->SW <= 0) return DH_EINVAL;
+  return launch_pool(*a, S(stream));
+}
+
+int dh_upsample2x_add_f32(const float* a, int lda, const float* b, int ldb, float* y, int ldy, int N, int H,
+                          int W, int C, void* stream) {
+  if (b == nullptr || y == nullptr) return DH_EINVAL;
+  return launch_upsample2x_add(a, lda, b, ldb, y, ldy, N, H, W, C, S(stream));
+}
+
+int dh_eltwise_f32(const dh_elt_args* a, void* stream) {
+  if (a == nullptr) return DH_EINVAL;
+  if ((a->scale == nullptr) != (a->shift == nullptr)) return DH_EINVAL;
+  return launch_eltwise(*a, S(stream));
+}
+
+int dh_softargmax2d_f32(const dh_sam_args* a, void* stream) {
+  if (a == nullptr) return DH_EINVAL;
+  return launch_softargmax2d(*a, S(stream));
+}
+
+int dh_context_aggregation_f32(const float* ys, const float* yc, const float* pc, float* y, int F, int J,
+                               int nctx, float alpha, int ldy, void* stream) {
+  if (ys == nullptr || yc == nullptr || pc == nullptr || y == nullptr || ldy < 2) return DH_EINVAL;
+  return launch_context_agg(ys, yc, pc, y, F, J, nctx, alpha, ldy, S(stream));
+}
+
+int dh_depth_means_f32(const float* h, int ldh, float* hxy, float* hz, int F, int HW, int D, int J,
+                       void* stream) {
+  if (h == nullptr || (hxy == nullptr && hz == nullptr)) return DH_EINVAL;
+  return launch_depth_means(h, ldh, hxy, hz, F, HW, D, J, S(stream));
+}
+
+int dh_softargmax1d_f32(const float* hz, const float* grid, float* z, int ldz, float* vz, int F, int D, int J,
+                        void* stream) {
+  if (hz == nullptr || grid == nullptr) return DH_EINVAL;
+  return launch_softargmax1d(hz, grid, z, ldz, vz, F, D, J, S(stream));
+}
+
+int dh_kronecker_f32(const float* hm, int ldh, const float* x, int ldx, float* f, int ldf, int B, int P, int J,
+                     int C, void* stream) {
+  if (hm == nullptr || x == nullptr || f == nullptr) return DH_EINVAL;
+  return launch_kronecker(hm, ldh, x, ldx, f, ldf, B, P, J, C, S(stream));
+}
+
+int dh_global_maxmin_softmax_f32(const float* x, int ldx, float* y, int B, int P, int C, int softmax,
+                                 void* stream) {
+  if (x == nullptr || y == nullptr) return DH_EINVAL;
+  return launch_global_maxmin_softmax(x, ldx, y, B, P, C, softmax, S(stream));
+}
+
+int dh_copy_channels_f32(const float* x, int ldx, float* y, int ldy, int64_t npix, int C, void* stream) {
+  if (x == nullptr || y == nullptr) return DH_EINVAL;
+  return launch_copy_channels(x, ldx, y, ldy, (long long)npix, C, S(stream));
+}
+
+int dh_zeropad2d_f32(const float* x, float* y, int B, int H, int W, int C, int OH, int OW, void* stream) {
+  if (x == nullptr || y == nullptr) return DH_EINVAL;
+  return launch_zeropad(x, y, B, H, W, C, OH, OW, S(stream));
+}
+
+// ---- graphs / events ---------------------------------------------------------------------------
+int dh_graph_begin_capture(void* stream) {
+  return rc_of(hipStreamBeginCapture(S(stream), hipStreamCaptureModeThreadLocal));
+}
+
+int dh_graph_end_capture(void* stream, void** graph_exec_out) {
+  if (graph_exec_out == nullptr) return DH_EINVAL;
+  hipGraph_t g = nullptr;
+  if (hipStreamEndCapture(S(stream), &g) != hipSuccess || g == nullptr) return DH_ELAUNCH;
+  hipGraphExec_t ge = nullptr;
+  hipError_t e = hipGraphInstantiate(&ge, g, nullptr, nullptr, 0);
+  hipGraphDestroy(g);
+  if (e != hipSuccess) return DH_ELAUNCH;
+  *graph_exec_out = ge;
+  return DH_OK;
+}
+
+int dh_graph_launch(void* graph_exec, void* stream) {
+  if (graph_exec == nullptr) return DH_EINVAL;
+  return rc_of(hipGraphLaunch(reinterpret_cast<hipGraphExec_t>(graph_exec), S(stream)));
+}
+
+int dh_graph_destroy(void* graph_exec) {
+  if (graph_exec == nullptr) return DH_OK;
+  return rc_of(hipGraphExecDestroy(reinterpret_cast<hipGraphExec_t>(graph_exec)));
+}
+
+int dh_event_create(void** event_out) {
+  if (event_out == nullptr) return DH_EINVAL;
+  hipEvent_t e;
+  if (hipEventCreate(&e) != hipSuccess) return DH_ELAUNCH;
+  *event_out = e;
+  return DH_OK;
+}
+int dh_event_record(void* event, void* stream) {
+  return rc_of(hipEventRecord(reinterpret_cast<hipEvent_t>(event), S(stream)));
+}
+int dh_event_synchronize(void* event) { return rc_of(hipEventSynchronize(reinterpret_cast<hipEvent_t>(event))); }
+int dh_event_elapsed_ms(void* start, void* stop, float* ms_out) {
+  if (ms_out == nullptr) return DH_EINVAL;
+  return rc_of(hipEventElapsedTime(ms_out, reinterpret_cast<hipEvent_t>(start), reinterpret_cast<hipEvent_t>(stop)));
+}
+int dh_event_destroy(void* event) { return rc_of(hipEventDestroy(reinterpret_cast<hipEvent_t>(event))); }
+int dh_stream_synchronize(void* stream) { return rc_of(hipStreamSynchronize(S(stream))); }
+
+}  // extern "C"

@@ -1,0 +1,332 @@
+// Heat-map -> key-point decoder kernels for gfx950 (the op the reference implements as a frozen
+// depthwise convolution with a whole-map kernel: deephar/layers.py:160-200, activations.py:3-30,
+// models/blocks.py:217-343, models/reception.py:167-222), the heat-map weighted feature pooling
+// (layers.py:478-508) and the tiny action-head reductions (layers.py:428-442, action.py:14-17).
+//
+// Heat-maps are NHWC: a pixel's C channels are contiguous, so lanes run over channels (coalesced) and
+// the spatial reduction runs over pixel-lanes: in-register partials -> wavefront __shfl_xor butterflies ->
+// one LDS hop across the workgroup's waves.
+#include "dh_kernels.h"
+
+namespace dh {
+namespace {
+
+constexpr int CG = 16;             // channels per workgroup
+constexpr int NTH = 256;           // threads per workgroup
+constexpr int PL = NTH / CG;       // pixel lanes per workgroup (16)
+constexpr int NW = NTH / 64;       // waves
+
+// Reduce across the lanes of a wave that share the same (tid % CG): xor 16 and 32.
+__device__ __forceinline__ float wave_max_cg(float v) {
+  v = fmaxf(v, __shfl_xor(v, 16));
+  v = fmaxf(v, __shfl_xor(v, 32));
+  return v;
+}
+__device__ __forceinline__ float wave_sum_cg(float v) {
+  v += __shfl_xor(v, 16);
+  v += __shfl_xor(v, 32);
+  return v;
+}
+
+// One workgroup = (frame f, group of CG channels).  Two passes over the (L2-resident) maps:
+//   pass 1: max of alpha*h (soft-max shift) and max 2x2-window sum of the raw map (confidence)
+//   pass 2: e = exp(alpha*h - max); sums of e, e*gx, e*gy; max 2x2-window sum of e; optional prob store
+__global__ __launch_bounds__(NTH) void softargmax2d_kernel(const SamArgs p) {
+  __shared__ float red[7][NW][CG];
+  const int tid = threadIdx.x;
+  const int cc = tid % CG, pl = tid / CG;
+  const int wave = tid >> 6;
+  const int groups = (p.C + CG - 1) / CG;
+  const int f = blockIdx.x / groups;
+  const int c = (blockIdx.x % groups) * CG + cc;
+  const bool cok = c < p.C;
+  const int HW = p.H * p.W;
+  const float* base = p.h + (size_t)f * HW * p.ldh + c;
+
+  float vmax = -INFINITY, cmax = -INFINITY, rmax = -INFINITY;
+  if (cok) {
+    for (int px = pl; px < HW; px += PL) {
+      const float v = base[(size_t)px * p.ldh];
+      vmax = fmaxf(vmax, p.alpha * v);
+      rmax = fmaxf(rmax, v);
+      if (p.conf_raw != nullptr) {
+        const int r = px / p.W, q = px - r * p.W;
+        if (r + 1 < p.H && q + 1 < p.W) {
+          const float s4 = ((v + base[(size_t)(px + 1) * p.ldh]) + base[(size_t)(px + p.W) * p.ldh]) +
+                           base[(size_t)(px + p.W + 1) * p.ldh];
+          cmax = fmaxf(cmax, p.conf_scale * s4);
+        }
+      }
+    }
+  }
+  vmax = wave_max_cg(vmax);
+  cmax = wave_max_cg(cmax);
+  rmax = wave_max_cg(rmax);
+  if ((tid & 63) < CG) { red[0][wave][cc] = vmax; red[1][wave][cc] = cmax; red[6][wave][cc] = rmax; }
+  __syncthreads();
+  vmax = red[0][0][cc]; cmax = red[1][0][cc]; rmax = red[6][0][cc];
+#pragma unroll
+  for (int w = 1; w < NW; ++w) {
+    vmax = fmaxf(vmax, red[0][w][cc]); cmax = fmaxf(cmax, red[1][w][cc]); rmax = fmaxf(rmax, red[6][w][cc]);
+  }
+  __syncthreads();
+
+  float s = 0.f, sx = 0.f, sy = 0.f, pmax = -INFINITY;
+  if (cok) {
+    for (int px = pl; px < HW; px += PL) {
+      const int r = px / p.W, q = px - r * p.W;
+      const float e = expf(p.alpha * base[(size_t)px * p.ldh] - vmax);
+      s += e;
+      sx = fmaf(e, p.gx[q], sx);
+      sy = fmaf(e, p.gy[r], sy);
+      if (p.conf_prob != nullptr && r + 1 < p.H && q + 1 < p.W) {
+        const float e1 = expf(p.alpha * base[(size_t)(px + 1) * p.ldh] - vmax);
+        const float e2 = expf(p.alpha * base[(size_t)(px + p.W) * p.ldh] - vmax);
+        const float e3 = expf(p.alpha * base[(size_t)(px + p.W + 1) * p.ldh] - vmax);
+        pmax = fmaxf(pmax, ((e + e1) + e2) + e3);
+      }
+    }
+  }
+  s = wave_sum_cg(s); sx = wave_sum_cg(sx); sy = wave_sum_cg(sy); pmax = wave_max_cg(pmax);
+  if ((tid & 63) < CG) {
+    red[2][wave][cc] = s; red[3][wave][cc] = sx; red[4][wave][cc] = sy; red[5][wave][cc] = pmax;
+  }
+  __syncthreads();
+  s = red[2][0][cc]; sx = red[3][0][cc]; sy = red[4][0][cc]; pmax = red[5][0][cc];
+#pragma unroll
+  for (int w = 1; w < NW; ++w) {
+    s += red[2][w][cc]; sx += red[3][w][cc]; sy += red[4][w][cc]; pmax = fmaxf(pmax, red[5][w][cc]);
+  }
+  s = fmaxf(s, 1e-7f);  // K.clip(sum, K.epsilon(), None), activations.py:12
+  const float inv = 1.f / s;
+
+  if (cok && pl == 0) {
+    if (p.xy != nullptr) {
+      float* o = p.xy + ((size_t)f * p.C + c) * p.ldxy;
+      o[0] = sx * inv;
+      o[1] = sy * inv;
+    }
+    if (p.conf_raw != nullptr) p.conf_raw[((size_t)f * p.C + c) * p.ldcr] = cmax;
+    if (p.conf_prob != nullptr) p.conf_prob[((size_t)f * p.C + c) * p.ldcp] = pmax * inv;
+    if (p.gmax != nullptr) p.gmax[(size_t)f * p.C + c] = rmax;
+  }
+  if (p.prob != nullptr && cok) {
+    float* pb = p.prob + (size_t)f * HW * p.ldp + c;
+    for (int px = pl; px < HW; px += PL)
+      pb[(size_t)px * p.ldp] = expf(p.alpha * base[(size_t)px * p.ldh] - vmax) * inv;
+  }
+}
+
+__global__ __launch_bounds__(256) void context_agg_kernel(const float* __restrict__ ys,
+                                                          const float* __restrict__ yc,
+                                                          const float* __restrict__ pc, float* __restrict__ y,
+                                                          int F, int J, int nctx, float alpha, int ldy) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= F * J) return;
+  const int f = idx / J, j = idx - f * J;
+  float sp = 0.f, spx = 0.f, spy = 0.f;
+  for (int k = 0; k < nctx; ++k) {
+    const size_t ci = (size_t)f * J * nctx + (size_t)j * nctx + k;
+    const float pk = pc[ci];
+    sp += pk;
+    spx += yc[ci * 2 + 0] * pk;
+    spy += yc[ci * 2 + 1] * pk;
+  }
+  const float xs = ys[(size_t)idx * 2 + 0], ysv = ys[(size_t)idx * 2 + 1];
+  y[(size_t)idx * ldy + 0] = alpha * xs + (1.f - alpha) * (spx / sp);
+  y[(size_t)idx * ldy + 1] = alpha * ysv + (1.f - alpha) * (spy / sp);
+}
+
+// hxy[f,p,j] = mean_d h[f,p,d*J+j]; hz[f,d,j] = mean_p h[f,p,d*J+j]
+// grid = (F, chunks of pixels); thread = channel (d*J+j) for hz partials via atomics-free two-stage:
+// stage A (this kernel, blockIdx.y = pixel chunk): hxy directly; hz partial sums into hz_part.
+__global__ __launch_bounds__(256) void depth_means_xy_kernel(const float* __restrict__ h, int ldh,
+                                                             float* __restrict__ hxy, int F, int HW, int D,
+                                                             int J) {
+  const long long total = (long long)F * HW * J;
+  const float invd = 1.f / (float)D;
+  for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += (long long)gridDim.x * blockDim.x) {
+    const int j = (int)(idx % J);
+    const long long px = idx / J;
+    const float* src = h + px * ldh + j;
+    float acc = 0.f;
+    for (int d = 0; d < D; ++d) acc += src[d * J];
+    hxy[idx] = acc * invd;
+  }
+}
+
+// one workgroup per frame; thread t owns channels t, t+256, ...; pixel loop is coalesced over channels
+__global__ __launch_bounds__(256) void depth_means_z_kernel(const float* __restrict__ h, int ldh,
+                                                            float* __restrict__ hz, int HW, int DJ) {
+  const int f = blockIdx.x;
+  const float inv = 1.f / (float)HW;
+  for (int c = threadIdx.x; c < DJ; c += blockDim.x) {
+    const float* src = h + (size_t)f * HW * ldh + c;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    int px = 0;
+    for (; px + 3 < HW; px += 4) {
+      a0 += src[(size_t)px * ldh];
+      a1 += src[(size_t)(px + 1) * ldh];
+      a2 += src[(size_t)(px + 2) * ldh];
+      a3 += src[(size_t)(px + 3) * ldh];
+    }
+    for (; px < HW; ++px) a0 += src[(size_t)px * ldh];
+    hz[(size_t)f * DJ + c] = ((a0 + a1) + (a2 + a3)) * inv;
+  }
+}
+
+__global__ __launch_bounds__(256) void softargmax1d_kernel(const float* __restrict__ hz,
+                                                           const float* __restrict__ grid,
+                                                           float* __restrict__ z, int ldz,
+                                                           float* __restrict__ vz, int F, int D, int J) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= F * J) return;
+  const int f = idx / J, j = idx - f * J;
+  const float* src = hz + (size_t)f * D * J + j;
+  float m = -INFINITY;
+  for (int d = 0; d < D; ++d) m = fmaxf(m, src[d * J]);
+  float s = 0.f, sz = 0.f;
+  for (int d = 0; d < D; ++d) {
+    const float e = expf(src[d * J] - m);
+    s += e;
+    sz = fmaf(e, grid[d], sz);
+  }
+  if (z != nullptr) z[(size_t)idx * ldz] = sz / s;
+  if (vz != nullptr) vz[idx] = m;
+}
+
+// f[b, j, c] = sum_p hm[b,p,j] * x[b,p,c].  Workgroup = (b, 64-channel slab); each thread owns one channel
+// and JT joints at a time; the heat-map tile for a chunk of pixels is staged in LDS and broadcast.
+constexpr int KR_PCH = 64;   // pixels per LDS chunk
+constexpr int KR_JMAX = 32;  // joints handled per pass
+__global__ __launch_bounds__(64) void kronecker_kernel(const float* __restrict__ hm, int ldh,
+                                                       const float* __restrict__ x, int ldx,
+                                                       float* __restrict__ f, int ldf, int P, int J, int C) {
+  __shared__ float sh[KR_PCH][KR_JMAX + 1];
+  const int b = blockIdx.y;
+  const int c = blockIdx.x * 64 + threadIdx.x;
+  const bool cok = c < C;
+  for (int j0 = 0; j0 < J; j0 += KR_JMAX) {
+    const int jn = min(KR_JMAX, J - j0);
+    float acc[KR_JMAX];
+#pragma unroll
+    for (int j = 0; j < KR_JMAX; ++j) acc[j] = 0.f;
+    for (int p0 = 0; p0 < P; p0 += KR_PCH) {
+      const int pn = min(KR_PCH, P - p0);
+      __syncthreads();
+      for (int i = threadIdx.x; i < pn * jn; i += 64) {
+        const int pp = i / jn, jj = i - pp * jn;
+        sh[pp][jj] = hm[((size_t)b * P + p0 + pp) * ldh + j0 + jj];
+      }
+      __syncthreads();
+      if (cok) {
+        for (int pp = 0; pp < pn; ++pp) {
+          const float xv = x[((size_t)b * P + p0 + pp) * ldx + c];
+#pragma unroll
+          for (int j = 0; j < KR_JMAX; ++j)
+            if (j < jn) acc[j] = fmaf(sh[pp][j], xv, acc[j]);
+        }
+      }
+    }
+    if (cok) {
+#pragma unroll
+      for (int j = 0; j < KR_JMAX; ++j)
+        if (j < jn) f[((size_t)b * J + j0 + j) * ldf + c] = acc[j];
+    }
+  }
+}
+
+// y[b, c] = softmax_c( max_p x[b,p,c] + min_p x[b,p,c] ); one workgroup per b, C <= 1024
+__global__ __launch_bounds__(256) void global_maxmin_softmax_kernel(const float* __restrict__ x, int ldx,
+                                                                    float* __restrict__ y, int P, int C,
+                                                                    int softmax) {
+  extern __shared__ float sv[];  // [C]
+  __shared__ float sred[4];
+  const int b = blockIdx.x;
+  for (int c = threadIdx.x; c < C; c += blockDim.x) {
+    float mx = -INFINITY, mn = INFINITY;
+    for (int p = 0; p < P; ++p) {
+      const float v = x[((size_t)b * P + p) * ldx + c];
+      mx = fmaxf(mx, v);
+      mn = fminf(mn, v);
+    }
+    sv[c] = mx + mn;
+  }
+  __syncthreads();
+  if (!softmax) {
+    for (int c = threadIdx.x; c < C; c += blockDim.x) y[(size_t)b * C + c] = sv[c];
+    return;
+  }
+  float m = -INFINITY;
+  for (int c = threadIdx.x; c < C; c += blockDim.x) m = fmaxf(m, sv[c]);
+  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+  if ((threadIdx.x & 63) == 0) sred[threadIdx.x >> 6] = m;
+  __syncthreads();
+  m = fmaxf(fmaxf(sred[0], sred[1]), fmaxf(sred[2], sred[3]));
+  __syncthreads();
+  float s = 0.f;
+  for (int c = threadIdx.x; c < C; c += blockDim.x) s += expf(sv[c] - m);
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+  if ((threadIdx.x & 63) == 0) sred[threadIdx.x >> 6] = s;
+  __syncthreads();
+  s = (sred[0] + sred[1]) + (sred[2] + sred[3]);
+  for (int c = threadIdx.x; c < C; c += blockDim.x) y[(size_t)b * C + c] = expf(sv[c] - m) / s;
+}
+
+}  // namespace
+
+int launch_softargmax2d(const SamArgs& a, hipStream_t s) {
+  if (a.F <= 0 || a.C <= 0 || a.H <= 0 || a.W <= 0 || a.h == nullptr || a.gx == nullptr || a.gy == nullptr)
+    return DH_EINVAL;
+  const long long blocks = (long long)a.F * ((a.C + CG - 1) / CG);
+  if (blocks > 0x7fffffffLL) return DH_EINVAL;
+  hipLaunchKernelGGL(softargmax2d_kernel, dim3((unsigned)blocks), dim3(NTH), 0, s, a);
+  return check_launch();
+}
+
+int launch_context_agg(const float* ys, const float* yc, const float* pc, float* y, int F, int J, int nctx,
+                       float alpha, int ldy, hipStream_t s) {
+  if (F <= 0 || J <= 0 || nctx <= 0) return DH_EINVAL;
+  hipLaunchKernelGGL(context_agg_kernel, dim3((F * J + 255) / 256), dim3(256), 0, s, ys, yc, pc, y, F, J, nctx,
+                     alpha, ldy);
+  return check_launch();
+}
+
+int launch_depth_means(const float* h, int ldh, float* hxy, float* hz, int F, int HW, int D, int J,
+                       hipStream_t s) {
+  if (F <= 0 || HW <= 0 || D <= 0 || J <= 0) return DH_EINVAL;
+  if (hxy != nullptr) {
+    long long g = ((long long)F * HW * J + 255) / 256;
+    if (g > 4096) g = 4096;
+    hipLaunchKernelGGL(depth_means_xy_kernel, dim3((unsigned)g), dim3(256), 0, s, h, ldh, hxy, F, HW, D, J);
+  }
+  if (hz != nullptr)
+    hipLaunchKernelGGL(depth_means_z_kernel, dim3(F), dim3(256), 0, s, h, ldh, hz, HW, D * J);
+  return check_launch();
+}
+
+int launch_softargmax1d(const float* hz, const float* grid, float* z, int ldz, float* vz, int F, int D, int J,
+                        hipStream_t s) {
+  if (F <= 0 || D <= 0 || J <= 0) return DH_EINVAL;
+  hipLaunchKernelGGL(softargmax1d_kernel, dim3((F * J + 255) / 256), dim3(256), 0, s, hz, grid, z, ldz, vz, F, D,
+                     J);
+  return check_launch();
+}
+
+int launch_kronecker(const float* hm, int ldh, const float* x, int ldx, float* f, int ldf, int B, int P, int J,
+                     int C, hipStream_t s) {
+  if (B <= 0 || P <= 0 || J <= 0 || C <= 0 || B > 65535) return DH_EINVAL;
+  hipLaunchKernelGGL(kronecker_kernel, dim3((C + 63) / 64, B), dim3(64), 0, s, hm, ldh, x, ldx, f, ldf, P, J, C);
+  return check_launch();
+}
+
+int launch_global_maxmin_softmax(const float* x, int ldx, float* y, int B, int P, int C, int softmax,
+                                 hipStream_t s) {
+  if (B <= 0 || P <= 0 || C <= 0 || C > 8192) return DH_EINVAL;
+  hipLaunchKernelGGL(global_maxmin_softmax_kernel, dim3(B), dim3(256), C * sizeof(float), s, x, ldx, y, P, C,
+                     softmax);
+  return check_launch();
+}
+
+}  // namespace dh

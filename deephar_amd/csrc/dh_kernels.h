@@ -1,0 +1,43 @@
+// Internal launch interface between the C-ABI layer (capi.hip) and the gfx950 kernels.
+// Argument structs are the public PODs of include/deephar_hip.h (documented there).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "deephar_hip.h"
+
+namespace dh {
+
+using ConvArgs = dh_conv_args;
+using DwArgs = dh_dw_args;
+using PoolArgs = dh_pool_args;
+using EltArgs = dh_elt_args;
+using SamArgs = dh_sam_args;
+
+int launch_conv_igemm(const ConvArgs& a, int cfg, hipStream_t s);
+int conv_igemm_pick_cfg(int M, int Cout);
+int conv_igemm_num_cfgs();
+int launch_dwconv(const DwArgs& a, hipStream_t s);
+int launch_pool(const PoolArgs& a, hipStream_t s);
+int launch_upsample2x_add(const float* a, int lda, const float* b, int ldb, float* y, int ldy, int N, int H,
+                          int W, int C, hipStream_t s);
+int launch_eltwise(const EltArgs& a, hipStream_t s);
+int launch_softargmax2d(const SamArgs& a, hipStream_t s);
+int launch_context_agg(const float* ys, const float* yc, const float* pc, float* y, int F, int J, int nctx,
+                       float alpha, int ldy, hipStream_t s);
+int launch_depth_means(const float* h, int ldh, float* hxy, float* hz, int F, int HW, int D, int J,
+                       hipStream_t s);
+int launch_softargmax1d(const float* hz, const float* grid, float* z, int ldz, float* vz, int F, int D, int J,
+                        hipStream_t s);
+int launch_kronecker(const float* hm, int ldh, const float* x, int ldx, float* f, int ldf, int B, int P, int J,
+                     int C, hipStream_t s);
+int launch_global_maxmin_softmax(const float* x, int ldx, float* y, int B, int P, int C, int softmax,
+                                 hipStream_t s);
+int launch_copy_channels(const float* x, int ldx, float* y, int ldy, long long npix, int C, hipStream_t s);
+int launch_zeropad(const float* x, float* y, int B, int H, int W, int C, int OH, int OW, hipStream_t s);
+
+inline int check_launch() {
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? DH_OK : DH_ELAUNCH;
+}
+
+}  // namespace dh

@@ -1,0 +1,305 @@
+// HBM-bound spatial kernels for gfx950: depthwise KxK conv, max / max+min pooling, nearest x2
+// up-sampling (+add), element-wise glue, channel-slab copies, zero padding.
+// All NHWC fp32; lanes run over channels (float4 = 16 B per lane, coalesced 128-B+ segments per pixel),
+// rows of the grid over pixels.  Replaces Keras SeparableConv2D's depthwise half, MaxPooling2D,
+// UpSampling2D, add, concatenate (reference deephar/layers.py:74-104, reception.py:74,86,108-127).
+#include "dh_kernels.h"
+
+namespace dh {
+namespace {
+
+__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
+__device__ __forceinline__ float4 fma4(float4 a, float4 b, float4 c) {
+  return make_float4(fmaf(a.x, b.x, c.x), fmaf(a.y, b.y, c.y), fmaf(a.z, b.z, c.z), fmaf(a.w, b.w, c.w));
+}
+__device__ __forceinline__ float4 max4(float4 a, float4 b) {
+  return make_float4(fmaxf(a.x, b.x), fmaxf(a.y, b.y), fmaxf(a.z, b.z), fmaxf(a.w, b.w));
+}
+__device__ __forceinline__ float4 min4(float4 a, float4 b) {
+  return make_float4(fminf(a.x, b.x), fminf(a.y, b.y), fminf(a.z, b.z), fminf(a.w, b.w));
+}
+
+// ------------------------------------------------------------------------------------------------
+// Depthwise conv.  Thread = (channel quad, output row, strip of TW output columns).  The strip walks a
+// sliding window along W so each input float4 is loaded once per (row, kh) instead of KW times.
+// ------------------------------------------------------------------------------------------------
+template <int KW, int TW>
+__global__ __launch_bounds__(256) void dwconv_kernel(const DwArgs p) {
+  const int c4n = p.C >> 2;
+  const int strips = (p.W + TW - 1) / TW;
+  const long long total = (long long)p.N * p.H * strips * c4n;
+  for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += (long long)gridDim.x * blockDim.x) {
+    const int c = (int)(idx % c4n) * 4;
+    long long t = idx / c4n;
+    const int st = (int)(t % strips); t /= strips;
+    const int oh = (int)(t % p.H);
+    const int n = (int)(t / p.H);
+    const int ow0 = st * TW;
+
+    float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f);
+    const bool aff = p.pre_scale != nullptr;
+    if (aff) { sc = ld4(p.pre_scale + c); sh = ld4(p.pre_shift + c); }
+
+    float4 acc[TW];
+#pragma unroll
+    for (int i = 0; i < TW; ++i) acc[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+
+    for (int kh = 0; kh < p.KH; ++kh) {
+      const int ih = oh - p.PT + kh;
+      if ((unsigned)ih >= (unsigned)p.H) continue;
+      const float* row = p.x + ((size_t)(n * p.H + ih) * p.W) * p.ldx + c;
+      float4 wv[KW];
+#pragma unroll
+      for (int kw = 0; kw < KW; ++kw) wv[kw] = ld4(p.w + (size_t)(kh * KW + kw) * p.C + c);
+#pragma unroll
+      for (int j = 0; j < TW + KW - 1; ++j) {
+        const int iw = ow0 - p.PL + j;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if ((unsigned)iw < (unsigned)p.W) {
+          v = ld4(row + (size_t)iw * p.ldx);
+          if (aff) v = fma4(v, sc, sh);
+          if (p.pre_relu) v = max4(v, make_float4(0.f, 0.f, 0.f, 0.f));
+        }
+#pragma unroll
+        for (int kw = 0; kw < KW; ++kw) {
+          const int o = j - kw;
+          if (o >= 0 && o < TW) acc[o] = fma4(v, wv[kw], acc[o]);
+        }
+      }
+    }
+    float* out = p.y + ((size_t)(n * p.H + oh) * p.W + ow0) * p.ldy + c;
+#pragma unroll
+    for (int i = 0; i < TW; ++i)
+      if (ow0 + i < p.W) st4(out + (size_t)i * p.ldy, acc[i]);
+  }
+}
+
+// Generic fallback (any KW, C not a multiple of 4): one thread per output element.
+__global__ __launch_bounds__(256) void dwconv_generic_kernel(const DwArgs p) {
+  const long long total = (long long)p.N * p.H * p.W * p.C;
+  for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += (long long)gridDim.x * blockDim.x) {
+    const int c = (int)(idx % p.C);
+    long long t = idx / p.C;
+    const int ow = (int)(t % p.W); t /= p.W;
+    const int oh = (int)(t % p.H);
+    const int n = (int)(t / p.H);
+    float acc = 0.f;
+    for (int kh = 0; kh < p.KH; ++kh) {
+      const int ih = oh - p.PT + kh;
+      if ((unsigned)ih >= (unsigned)p.H) continue;
+      for (int kw = 0; kw < p.KW; ++kw) {
+        const int iw = ow - p.PL + kw;
+        if ((unsigned)iw >= (unsigned)p.W) continue;
+        float v = p.x[((size_t)(n * p.H + ih) * p.W + iw) * p.ldx + c];
+        if (p.pre_scale != nullptr) v = fmaf(v, p.pre_scale[c], p.pre_shift[c]);
+        if (p.pre_relu) v = fmaxf(v, 0.f);
+        acc = fmaf(v, p.w[(size_t)(kh * p.KW + kw) * p.C + c], acc);
+      }
+    }
+    p.y[((size_t)(n * p.H + oh) * p.W + ow) * p.ldy + c] = acc;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+template <bool VEC>
+__global__ __launch_bounds__(256) void pool_kernel(const PoolArgs p) {
+  constexpr int V = VEC ? 4 : 1;
+  const int cn = p.C / V;
+  const long long total = (long long)p.N * p.OH * p.OW * cn;
+  for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += (long long)gridDim.x * blockDim.x) {
+    const int c = (int)(idx % cn) * V;
+    long long t = idx / cn;
+    const int ow = (int)(t % p.OW); t /= p.OW;
+    const int oh = (int)(t % p.OH);
+    const int n = (int)(t / p.OH);
+    float4 mx = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+    float4 mn = make_float4(INFINITY, INFINITY, INFINITY, INFINITY);
+    for (int kh = 0; kh < p.KH; ++kh) {
+      const int ih = oh * p.SH - p.PT + kh;
+      if ((unsigned)ih >= (unsigned)p.H) continue;
+      for (int kw = 0; kw < p.KW; ++kw) {
+        const int iw = ow * p.SW - p.PL + kw;
+        if ((unsigned)iw >= (unsigned)p.W) continue;
+        const float* src = p.x + ((size_t)(n * p.H + ih) * p.W + iw) * p.ldx + c;
+        float4 v;
+        if constexpr (VEC) v = ld4(src);
+        else v = make_float4(*src, 0.f, 0.f, 0.f);
+        mx = max4(mx, v);
+        mn = min4(mn, v);
+      }
+    }
+    float4 r = mx;
+    if (p.mode == 1) r = make_float4(mx.x + mn.x, mx.y + mn.y, mx.z + mn.z, mx.w + mn.w);
+    float* dst = p.y + ((size_t)(n * p.OH + oh) * p.OW + ow) * p.ldy + c;
+    if constexpr (VEC) st4(dst, r);
+    else *dst = r.x;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+template <bool VEC>
+__global__ __launch_bounds__(256) void upsample2x_add_kernel(const float* __restrict__ a, int lda,
+                                                             const float* __restrict__ b, int ldb,
+                                                             float* __restrict__ y, int ldy, int N, int H,
+                                                             int W, int C) {
+  constexpr int V = VEC ? 4 : 1;
+  const int cn = C / V;
+  const long long total = (long long)N * H * W * cn;
+  for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += (long long)gridDim.x * blockDim.x) {
+    const int c = (int)(idx % cn) * V;
+    long long t = idx / cn;
+    const int w = (int)(t % W); t /= W;
+    const int h = (int)(t % H);
+    const int n = (int)(t / H);
+    const size_t po = (size_t)(n * H + h) * W + w;
+    const size_t pb = (size_t)(n * (H >> 1) + (h >> 1)) * (W >> 1) + (w >> 1);
+    if constexpr (VEC) {
+      float4 v = ld4(b + pb * ldb + c);
+      if (a != nullptr) {
+        const float4 u = ld4(a + po * lda + c);
+        v = make_float4(u.x + v.x, u.y + v.y, u.z + v.z, u.w + v.w);
+      }
+      st4(y + po * ldy + c, v);
+    } else {
+      float v = b[pb * ldb + c];
+      if (a != nullptr) v = a[po * lda + c] + v;
+      y[po * ldy + c] = v;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void eltwise_kernel(const EltArgs p) {
+  const long long total = p.npix * p.C;
+  for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += (long long)gridDim.x * blockDim.x) {
+    const int c = (int)(idx % p.C);
+    const long long px = idx / p.C;
+    float v = p.a[px * p.lda + c];
+    if (p.scale != nullptr) v = v * p.scale[c] + p.shift[c];
+    if (p.op == 0) {
+      if (p.b != nullptr) v += p.b[px * p.ldb + (p.bcast_b ? 0 : c)];
+      if (p.c != nullptr) v += p.c[px * p.ldc + c];
+    } else if (p.op == 1) {
+      v *= p.b[px * p.ldb + (p.bcast_b ? 0 : c)];
+    } else if (p.op == 2) {
+      if (p.b != nullptr) v += p.b[px * p.ldb + (p.bcast_b ? 0 : c)];
+      v = 1.f / (1.f + expf(-v));
+    }
+    if (p.relu) v = fmaxf(v, 0.f);
+    p.y[px * p.ldy + c] = v;
+  }
+}
+
+template <bool VEC>
+__global__ __launch_bounds__(256) void copy_channels_kernel(const float* __restrict__ x, int ldx,
+                                                            float* __restrict__ y, int ldy, long long npix,
+                                                            int C) {
+  constexpr int V = VEC ? 4 : 1;
+  const int cn = C / V;
+  const long long total = npix * cn;
+  for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += (long long)gridDim.x * blockDim.x) {
+    const int c = (int)(idx % cn) * V;
+    const long long px = idx / cn;
+    if constexpr (VEC) st4(y + px * ldy + c, ld4(x + px * ldx + c));
+    else y[px * ldy + c] = x[px * ldx + c];
+  }
+}
+
+__global__ __launch_bounds__(256) void zeropad_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                      int B, int H, int W, int C, int OH, int OW) {
+  const long long total = (long long)B * OH * OW * C;
+  for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += (long long)gridDim.x * blockDim.x) {
+    const int c = (int)(idx % C);
+    long long t = idx / C;
+    const int w = (int)(t % OW); t /= OW;
+    const int h = (int)(t % OH);
+    const int b = (int)(t / OH);
+    y[idx] = (h < H && w < W) ? x[((size_t)(b * H + h) * W + w) * C + c] : 0.f;
+  }
+}
+
+inline unsigned grid_for(long long total, int block = 256) {
+  long long g = (total + block - 1) / block;
+  const long long cap = 256LL * 16;  // 256 CUs x 16 workgroups, grid-stride beyond that
+  if (g > cap) g = cap;
+  if (g < 1) g = 1;
+  return (unsigned)g;
+}
+
+inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+}  // namespace
+
+int launch_dwconv(const DwArgs& a, hipStream_t s) {
+  if (a.N <= 0 || a.C <= 0 || a.KH <= 0 || a.KW <= 0) return DH_EINVAL;
+  const bool vec = (a.C % 4 == 0) && (a.ldx % 4 == 0) && (a.ldy % 4 == 0) && al16(a.x) && al16(a.y) &&
+                   al16(a.w) && (a.pre_scale == nullptr || (al16(a.pre_scale) && al16(a.pre_shift)));
+  if (vec && (a.KW == 5 || a.KW == 3 || a.KW == 1)) {
+    constexpr int TW = 4;
+    const long long total = (long long)a.N * a.H * ((a.W + TW - 1) / TW) * (a.C / 4);
+    if (a.KW == 5) hipLaunchKernelGGL((dwconv_kernel<5, TW>), dim3(grid_for(total)), dim3(256), 0, s, a);
+    else if (a.KW == 3) hipLaunchKernelGGL((dwconv_kernel<3, TW>), dim3(grid_for(total)), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((dwconv_kernel<1, TW>), dim3(grid_for(total)), dim3(256), 0, s, a);
+  } else {
+    const long long total = (long long)a.N * a.H * a.W * a.C;
+    hipLaunchKernelGGL(dwconv_generic_kernel, dim3(grid_for(total)), dim3(256), 0, s, a);
+  }
+  return check_launch();
+}
+
+int launch_pool(const PoolArgs& a, hipStream_t s) {
+  if (a.N <= 0 || a.C <= 0 || a.OH <= 0 || a.OW <= 0) return DH_EINVAL;
+  const bool vec = (a.C % 4 == 0) && (a.ldx % 4 == 0) && (a.ldy % 4 == 0) && al16(a.x) && al16(a.y);
+  const long long total = (long long)a.N * a.OH * a.OW * (vec ? a.C / 4 : a.C);
+  if (vec) hipLaunchKernelGGL(pool_kernel<true>, dim3(grid_for(total)), dim3(256), 0, s, a);
+  else hipLaunchKernelGGL(pool_kernel<false>, dim3(grid_for(total)), dim3(256), 0, s, a);
+  return check_launch();
+}
+
+int launch_upsample2x_add(const float* a, int lda, const float* b, int ldb, float* y, int ldy, int N, int H,
+                          int W, int C, hipStream_t s) {
+  if (N <= 0 || C <= 0 || (H & 1) || (W & 1)) return DH_EINVAL;
+  const bool vec = (C % 4 == 0) && (ldb % 4 == 0) && (ldy % 4 == 0) && al16(b) && al16(y) &&
+                   (a == nullptr || ((lda % 4 == 0) && al16(a)));
+  const long long total = (long long)N * H * W * (vec ? C / 4 : C);
+  if (vec)
+    hipLaunchKernelGGL(upsample2x_add_kernel<true>, dim3(grid_for(total)), dim3(256), 0, s, a, lda, b, ldb, y,
+                       ldy, N, H, W, C);
+  else
+    hipLaunchKernelGGL(upsample2x_add_kernel<false>, dim3(grid_for(total)), dim3(256), 0, s, a, lda, b, ldb, y,
+                       ldy, N, H, W, C);
+  return check_launch();
+}
+
+int launch_eltwise(const EltArgs& a, hipStream_t s) {
+  if (a.npix <= 0 || a.C <= 0 || a.a == nullptr || a.y == nullptr) return DH_EINVAL;
+  if (a.op == 1 && a.b == nullptr) return DH_EINVAL;
+  hipLaunchKernelGGL(eltwise_kernel, dim3(grid_for(a.npix * a.C)), dim3(256), 0, s, a);
+  return check_launch();
+}
+
+int launch_copy_channels(const float* x, int ldx, float* y, int ldy, long long npix, int C, hipStream_t s) {
+  if (npix <= 0 || C <= 0) return DH_EINVAL;
+  const bool vec = (C % 4 == 0) && (ldx % 4 == 0) && (ldy % 4 == 0) && al16(x) && al16(y);
+  const long long total = npix * (vec ? C / 4 : C);
+  if (vec) hipLaunchKernelGGL(copy_channels_kernel<true>, dim3(grid_for(total)), dim3(256), 0, s, x, ldx, y, ldy, npix, C);
+  else hipLaunchKernelGGL(copy_channels_kernel<false>, dim3(grid_for(total)), dim3(256), 0, s, x, ldx, y, ldy, npix, C);
+  return check_launch();
+}
+
+int launch_zeropad(const float* x, float* y, int B, int H, int W, int C, int OH, int OW, hipStream_t s) {
+  if (B <= 0 || C <= 0 || OH < H || OW < W) return DH_EINVAL;
+  hipLaunchKernelGGL(zeropad_kernel, dim3(grid_for((long long)B * OH * OW * C)), dim3(256), 0, s, x, y, B, H, W, C,
+                     OH, OW);
+  return check_launch();
+}
+
+}  // namespace dh

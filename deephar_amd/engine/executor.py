@@ -1,0 +1,405 @@
+"""Bind a Plan to device memory for a batch size and run it through the C-ABI on one HIP stream.
+
+PyTorch-ROCm is used for exactly three things: the activation arena / weight tensors (device memory),
+the stream handle, and host<->device copies.  Every kernel is a libdeephar_hip.so entry point; there is no
+torch compute and no CPU fallback.  The launch sequence of a bound plan is captured once into a hipGraph
+(dh_graph_*), so steady-state `predict` costs one graph launch per batch instead of ~300 kernel launches.
+"""
+import ctypes as C
+
+import numpy as np
+
+from .. import _lib
+from . import packing
+
+BN_EPS = 1e-3  # keras BatchNormalization default epsilon
+
+
+def _torch():
+    import torch
+    return torch
+
+
+class WeightStore:
+    """Device copies of the model weights in kernel-ready layout; refreshed in place when Params change."""
+
+    def __init__(self, device):
+        self.device = device
+        self.conv = {}    # id(param) -> (tensor, Kp, Np, version)
+        self.dw = {}      # id(param) -> (tensor, version)
+        self.bn = {}      # id(layer) -> (scale, shift, versions)
+        self.const = {}   # key -> tensor
+
+    def _dev(self, arr):
+        torch = _torch()
+        return torch.from_numpy(np.ascontiguousarray(arr, dtype=np.float32)).to(self.device)
+
+    @staticmethod
+    def _require(p):
+        if p.value is None:
+            raise RuntimeError('weight %s is not set: call model.load_weights(...) or '
+                               'deephar_amd.weights.init_synthetic(model) before predict' % p.key)
+        return p.value
+
+    def conv_weight(self, p):
+        ent = self.conv.get(id(p))
+        if ent is None or ent[3] != p.version:
+            packed, kp, np_ = packing.pack_conv(self._require(p))
+            if ent is None:
+                ent = (self._dev(packed), kp, np_, p.version)
+            else:
+                ent[0].copy_(self._dev(packed))
+                ent = (ent[0], kp, np_, p.version)
+            self.conv[id(p)] = ent
+        return ent[0], ent[1], ent[2]
+
+    def dw_weight(self, p):
+        ent = self.dw.get(id(p))
+        if ent is None or ent[1] != p.version:
+            w = self._require(p)
+            flat = np.ascontiguousarray(w.reshape(w.shape[0] * w.shape[1], w.shape[2]))
+            if ent is None:
+                ent = (self._dev(flat), p.version)
+            else:
+                ent[0].copy_(self._dev(flat))
+                ent = (ent[0], p.version)
+            self.dw[id(p)] = ent
+        return ent[0]
+
+    def bn_affine(self, layer):
+        """BatchNormalization inference as y = x*scale + shift (fp32, like tf.nn.batch_normalization)."""
+        vers = tuple(p.version for p in layer.params)
+        ent = self.bn.get(id(layer))
+        if ent is None or ent[2] != vers:
+            byrole = {p.role: self._require(p) for p in layer.params}
+            inv = (np.float32(1.0) / np.sqrt(byrole['var'].astype(np.float32) + np.float32(BN_EPS))).astype(np.float32)
+            if 'gamma' in byrole:
+                inv = (inv * byrole['gamma']).astype(np.float32)
+            shift = (byrole['beta'] - byrole['mean'] * inv).astype(np.float32)
+            if ent is None:
+                ent = (self._dev(inv), self._dev(shift), vers)
+            else:
+                ent[0].copy_(self._dev(inv))
+                ent[1].copy_(self._dev(shift))
+                ent = (ent[0], ent[1], vers)
+            self.bn[id(layer)] = ent
+        return ent[0], ent[1]
+
+    def constant(self, key, make):
+        t = self.const.get(key)
+        if t is None:
+            t = self._dev(make())
+            self.const[key] = t
+        return t
+
+
+def grid_x(w):
+    """float32 x grid of utils/math.py:6-19 (np.linspace(0,1,W) stored into a float32 array)."""
+    return np.linspace(0.0, 1.0, num=w).astype(np.float32)
+
+
+def grid_depth(d):
+    """layers.py:141-143: linspace(1/(2D), 1-1/(2D), D) stored in float32 Conv1D weights."""
+    s = 1 / (2 * d)
+    return np.linspace(s, 1 - s, num=d).astype(np.float32)
+
+
+class BoundPlan:
+    """A Plan with concrete device pointers for batch size n."""
+
+    def __init__(self, plan, n, store, device):
+        torch = _torch()
+        self.plan, self.n, self.store, self.device = plan, n, store, device
+        self.lib = _lib.load()
+        self.arena = torch.empty(max(plan.arena_items * n, 4), dtype=torch.float32, device=device)
+        self.base = self.arena.data_ptr()
+        self.calls = []       # (fn, args tuple without stream, step)
+        self._keep = []       # ctypes structs kept alive
+        self.graph = None
+        for step in plan.steps:
+            self._bind(step)
+
+    # ---- views -------------------------------------------------------------------------------------------
+    def ptr(self, v):
+        return self.base + 4 * (v.buf.offset * self.n + v.coff)
+
+    def tensor(self, v):
+        """torch view [n, *shape] of a Value (strided when it lives inside a wider buffer)."""
+        torch = _torch()
+        shape = (self.n,) + v.shape
+        strides = [1] * len(shape)
+        strides[-1] = 1
+        if len(shape) >= 2:
+            strides[-2] = v.ld
+            for i in range(len(shape) - 3, -1, -1):
+                strides[i] = strides[i + 1] * shape[i + 1]
+        return torch.as_strided(self.arena, shape, strides, v.buf.offset * self.n + v.coff)
+
+    # ---- binding -----------------------------------------------------------------------------------------
+    def _bind(self, s):
+        lib, n, k = self.lib, self.n, s.kind
+        a = s.attrs
+        P = self.ptr
+
+        def opt(role, d=s.ins):
+            v = d.get(role)
+            return P(v) if v is not None else None
+
+        if k == 'conv':
+            x, y = s.ins['x'], s.outs['y']
+            wt, kp, np_ = self.store.conv_weight(s.params['w'])
+            args = _lib.ConvArgs()
+            args.x, args.w, args.y = P(x), wt.data_ptr(), P(y)
+            if 'pre_bn' in s.params:
+                sc, sh = self.store.bn_affine(s.params['pre_bn'])
+                args.pre_scale, args.pre_shift = sc.data_ptr(), sh.data_ptr()
+            if 'post_bn' in s.params:
+                sc, sh = self.store.bn_affine(s.params['post_bn'])
+                args.post_scale, args.post_shift = sc.data_ptr(), sh.data_ptr()
+            up = 2 if a['up2'] else 1
+            args.N = n * x.lead(3)
+            args.H, args.W, args.Cin, args.ldx = x.shape[-3], x.shape[-2], x.C, x.ld
+            args.OH, args.OW, args.Cout, args.ldy = y.shape[-3] // up, y.shape[-2] // up, a['Cout'], y.ld
+            args.KH, args.KW, args.SH, args.SW, args.PT, args.PL = a['kh'], a['kw'], a['sh'], a['sw'], a['pt'], a['pl']
+            args.K, args.Kp, args.Np = a['K'], kp, np_
+            r1, r2 = s.ins.get('res1'), s.ins.get('res2')
+            if r1 is not None:
+                args.res1, args.ldr1 = P(r1), r1.ld
+            if r2 is not None:
+                args.res2, args.ldr2 = P(r2), r2.ld
+            args.pre_relu, args.post_relu, args.up2 = a['pre_relu'], a['post_relu'], a['up2']
+            self._keep.append(args)
+            self.calls.append((lib.dh_conv2d_f32, (C.byref(args), a.get('tile_cfg', -1)), s))
+        elif k == 'dwconv':
+            x, y = s.ins['x'], s.outs['y']
+            args = _lib.DwArgs()
+            args.x, args.w, args.y = P(x), self.store.dw_weight(s.params['w']).data_ptr(), P(y)
+            if 'pre_bn' in s.params:
+                sc, sh = self.store.bn_affine(s.params['pre_bn'])
+                args.pre_scale, args.pre_shift = sc.data_ptr(), sh.data_ptr()
+            args.N, args.H, args.W, args.C = n * x.lead(3), x.shape[-3], x.shape[-2], x.C
+            args.ldx, args.ldy = x.ld, y.ld
+            args.KH, args.KW, args.PT, args.PL, args.pre_relu = a['kh'], a['kw'], a['pt'], a['pl'], a['pre_relu']
+            self._keep.append(args)
+            self.calls.append((lib.dh_dwconv2d_f32, (C.byref(args),), s))
+        elif k == 'pool':
+            x, y = s.ins['x'], s.outs['y']
+            args = _lib.PoolArgs()
+            args.x, args.y = P(x), P(y)
+            args.N, args.H, args.W, args.C, args.ldx = n * x.lead(3), x.shape[-3], x.shape[-2], x.C, x.ld
+            args.OH, args.OW, args.ldy = y.shape[-3], y.shape[-2], y.ld
+            args.KH, args.KW, args.SH, args.SW, args.PT, args.PL = a['kh'], a['kw'], a['sh'], a['sw'], a['pt'], a['pl']
+            args.mode = a.get('mode', 0)
+            self._keep.append(args)
+            self.calls.append((lib.dh_pool2d_f32, (C.byref(args),), s))
+        elif k == 'upsample_add':
+            b, y = s.ins['b'], s.outs['y']
+            av = s.ins.get('a')
+            self.calls.append((lib.dh_upsample2x_add_f32,
+                               (P(av) if av is not None else None, av.ld if av is not None else 0, P(b), b.ld,
+                                P(y), y.ld, n * y.lead(3), y.shape[-3], y.shape[-2], y.C), s))
+        elif k == 'eltwise':
+            av, y = s.ins['a'], s.outs['y']
+            args = _lib.EltArgs()
+            args.a, args.y, args.lda, args.ldy = P(av), P(y), av.ld, y.ld
+            bv, cv = s.ins.get('b'), s.ins.get('c')
+            if bv is not None:
+                args.b, args.ldb = P(bv), bv.ld
+            if cv is not None:
+                args.c, args.ldc = P(cv), cv.ld
+            if 'bn' in s.params:
+                sc, sh = self.store.bn_affine(s.params['bn'])
+                args.scale, args.shift = sc.data_ptr(), sh.data_ptr()
+            args.npix, args.C = n * av.npix, av.C
+            args.relu, args.op, args.bcast_b = a.get('relu', 0), a.get('op', 0), a.get('bcast_b', 0)
+            self._keep.append(args)
+            self.calls.append((lib.dh_eltwise_f32, (C.byref(args),), s))
+        elif k == 'sam':
+            h = s.ins['h']
+            H, W = h.shape[-3], h.shape[-2]
+            args = _lib.SamArgs()
+            args.h = P(h)
+            args.gx = self.store.constant(('gx', W), lambda: grid_x(W)).data_ptr()
+            args.gy = self.store.constant(('gx', H), lambda: grid_x(H)).data_ptr()
+            o = s.outs
+            if o.get('xy') is not None:
+                args.xy, args.ldxy = P(o['xy']), o['xy'].ld
+            if o.get('conf_raw') is not None:
+                args.conf_raw, args.ldcr = P(o['conf_raw']), o['conf_raw'].ld
+            if o.get('conf_prob') is not None:
+                args.conf_prob, args.ldcp = P(o['conf_prob']), o['conf_prob'].ld
+            if o.get('prob') is not None:
+                args.prob, args.ldp = P(o['prob']), o['prob'].ld
+            if o.get('gmax') is not None:
+                assert o['gmax'].dense
+                args.gmax = P(o['gmax'])
+            args.F, args.H, args.W, args.C, args.ldh = n * h.lead(3), H, W, h.C, h.ld
+            args.alpha, args.conf_scale = a['alpha'], a['conf_scale']
+            self._keep.append(args)
+            self.calls.append((lib.dh_softargmax2d_f32, (C.byref(args),), s))
+        elif k == 'context_agg':
+            ys, y = s.ins['ys'], s.outs['y']
+            self.calls.append((lib.dh_context_aggregation_f32,
+                               (P(ys), P(s.ins['yc']), P(s.ins['pc']), P(y), n * ys.lead(2), ys.shape[-2],
+                                a['nctx'], a['alpha'], y.ld), s))
+        elif k == 'depth_means':
+            h = s.ins['h']
+            self.calls.append((lib.dh_depth_means_f32,
+                               (P(h), h.ld, opt('hxy', s.outs), opt('hz', s.outs), n * h.lead(3),
+                                h.shape[-3] * h.shape[-2], a['D'], a['J']), s))
+        elif k == 'softargmax1d':
+            hz = s.ins['hz']
+            D, J = hz.shape[-2], hz.shape[-1]
+            grid = self.store.constant(('gd', D), lambda: grid_depth(D))
+            z = s.outs.get('z')
+            self.calls.append((lib.dh_softargmax1d_f32,
+                               (P(hz), grid.data_ptr(), P(z) if z is not None else None,
+                                z.ld if z is not None else 1, opt('vz', s.outs), n * hz.lead(2), D, J), s))
+        elif k == 'kronecker':
+            hm, x, y = s.ins['hm'], s.ins['x'], s.outs['y']
+            self.calls.append((lib.dh_kronecker_f32,
+                               (P(hm), hm.ld, P(x), x.ld, P(y), y.ld, n * hm.lead(3),
+                                hm.shape[-3] * hm.shape[-2], hm.C, x.C), s))
+        elif k == 'globalmaxmin':
+            x, y = s.ins['x'], s.outs['y']
+            self.calls.append((lib.dh_global_maxmin_softmax_f32,
+                               (P(x), x.ld, P(y), n * x.lead(3), x.shape[-3] * x.shape[-2], x.C, a['softmax']), s))
+        elif k == 'copy':
+            x, y = s.ins['x'], s.outs['y']
+            self.calls.append((lib.dh_copy_channels_f32, (P(x), x.ld, P(y), y.ld, n * x.npix, x.C), s))
+        elif k == 'zeropad':
+            x, y = s.ins['x'], s.outs['y']
+            self.calls.append((lib.dh_zeropad2d_f32,
+                               (P(x), P(y), n * x.lead(3), x.shape[-3], x.shape[-2], x.C, y.shape[-3],
+                                y.shape[-2]), s))
+        else:
+            raise NotImplementedError('no binding for step kind %r' % k)
+
+    # ---- execution -----------------------------------------------------------------------------------------
+    def launch_all(self, stream_ptr):
+        for fn, args, step in self.calls:
+            rc = fn(*args, stream_ptr)
+            if rc != 0:
+                _lib.check(rc, 'step %s (%s)' % (step.kind, step.name))
+
+    def capture(self, stream_ptr):
+        lib = self.lib
+        _lib.check(lib.dh_graph_begin_capture(stream_ptr), 'graph capture begin')
+        try:
+            self.launch_all(stream_ptr)
+        finally:
+            g = C.c_void_p()
+            rc = lib.dh_graph_end_capture(stream_ptr, C.byref(g))
+        _lib.check(rc, 'graph capture end')
+        self.graph = g
+
+    def replay(self, stream_ptr):
+        _lib.check(self.lib.dh_graph_launch(self.graph, stream_ptr), 'graph launch')
+
+    def profile(self, stream_ptr, reps=1):
+        """Per-step device time (ms, mean over reps) with HIP events recorded on the launch stream."""
+        lib = self.lib
+        evs = []
+        for _ in range(len(self.calls) + 1):
+            e = C.c_void_p()
+            _lib.check(lib.dh_event_create(C.byref(e)))
+            evs.append(e)
+        times = np.zeros(len(self.calls))
+        for _ in range(reps):
+            _lib.check(lib.dh_event_record(evs[0], stream_ptr))
+            for i, (fn, args, step) in enumerate(self.calls):
+                _lib.check(fn(*args, stream_ptr), step.kind)
+                _lib.check(lib.dh_event_record(evs[i + 1], stream_ptr))
+            _lib.check(lib.dh_event_synchronize(evs[-1]))
+            for i in range(len(self.calls)):
+                ms = C.c_float()
+                _lib.check(lib.dh_event_elapsed_ms(evs[i], evs[i + 1], C.byref(ms)))
+                times[i] += ms.value
+        for e in evs:
+            lib.dh_event_destroy(e)
+        return times / reps
+
+    def __del__(self):
+        try:
+            if self.graph is not None:
+                self.lib.dh_graph_destroy(self.graph)
+        except Exception:
+            pass
+
+
+class Executor:
+    def __init__(self, plan, device=None, use_graph=True):
+        torch = _torch()
+        if not torch.cuda.is_available():
+            raise _lib.DeepharHipError('no HIP device visible: deephar_amd runs only on an AMD GPU (gfx950); '
+                                       'there is no CPU execution path')
+        _lib.load()
+        self.device = torch.device(device or 'cuda:%d' % torch.cuda.current_device())
+        self.plan = plan
+        self.use_graph = use_graph
+        self.store = WeightStore(self.device)
+        self.bound = {}
+        with torch.cuda.device(self.device):
+            self.stream = torch.cuda.Stream(device=self.device)
+
+    @property
+    def stream_ptr(self):
+        return self.stream.cuda_stream
+
+    def bind(self, n):
+        bp = self.bound.get(n)
+        if bp is None:
+            torch = _torch()
+            with torch.cuda.device(self.device), torch.cuda.stream(self.stream):
+                bp = BoundPlan(self.plan, n, self.store, self.device)
+            self.bound[n] = bp
+        return bp
+
+    def refresh_weights(self):
+        """Push changed Params to their (already bound) device tensors in place."""
+        torch = _torch()
+        with torch.cuda.device(self.device), torch.cuda.stream(self.stream):
+            for s in self.plan.steps:
+                for role, p in s.params.items():
+                    if role == 'w':
+                        (self.store.dw_weight if s.kind == 'dwconv' else self.store.conv_weight)(p)
+                    else:
+                        self.store.bn_affine(p)
+        self.stream.synchronize()
+
+    def set_inputs(self, bp, arrays):
+        """Copy host (or device) arrays [m<=n, ...] into the input buffers (fp32)."""
+        torch = _torch()
+        for v, arr in zip(self.plan.inputs, arrays):
+            dst = bp.tensor(v)
+            if isinstance(arr, np.ndarray):
+                src = torch.from_numpy(np.ascontiguousarray(arr))
+            else:
+                src = arr
+            m = src.shape[0]
+            if tuple(src.shape[1:]) != tuple(dst.shape[1:]) or m > bp.n:
+                raise ValueError('input has shape %s, model expects [<=%d, %s]' % (tuple(src.shape), bp.n,
+                                                                                  tuple(dst.shape[1:])))
+            dst[:m].copy_(src.to(self.device, non_blocking=True).to(torch.float32))
+
+    def forward(self, bp):
+        """Enqueue one forward pass of the bound plan on the executor stream."""
+        if self.use_graph:
+            if bp.graph is None:
+                bp.capture(self.stream_ptr)
+            bp.replay(self.stream_ptr)
+        else:
+            bp.launch_all(self.stream_ptr)
+
+    def run(self, arrays, n=None):
+        """arrays: list of host arrays with equal leading dim m.  Returns list of np.float32 outputs."""
+        torch = _torch()
+        m = arrays[0].shape[0]
+        n = n or m
+        with torch.cuda.device(self.device), torch.cuda.stream(self.stream):
+            bp = self.bind(n)
+            self.set_inputs(bp, arrays)
+            self.forward(bp)
+            outs = [bp.tensor(v)[:m].contiguous().cpu() for v in self.plan.outputs]
+        self.stream.synchronize()
+        return [o.numpy() for o in outs]

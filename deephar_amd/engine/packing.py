@@ -1,0 +1,28 @@
+"""Host-side weight re-layout for the gfx950 kernels (delegates to the C-ABI so that other hosts get the
+exact same packing: dh_conv2d_pack_weights_host)."""
+import ctypes as C
+
+import numpy as np
+
+from .. import _lib
+
+
+def pack_conv(w_hwio):
+    """Keras HWIO conv kernel [kh,kw,cin,cout] -> ([Kp/4][Np][4] float32 flat array, Kp, Np)."""
+    lib = _lib.load()
+    w = np.ascontiguousarray(w_hwio, dtype=np.float32)
+    kh, kw, cin, cout = w.shape
+    kp, np_ = C.c_int(), C.c_int()
+    _lib.check(lib.dh_conv2d_packed_dims(kh, kw, cin, cout, C.byref(kp), C.byref(np_)), 'packed_dims')
+    out = np.empty(kp.value * np_.value, dtype=np.float32)
+    _lib.check(lib.dh_conv2d_pack_weights_host(w.ctypes.data, out.ctypes.data, kh, kw, cin, cout), 'pack')
+    return out, kp.value, np_.value
+
+
+def unpack_conv(packed, kh, kw, cin, cout):
+    """Inverse of pack_conv (tests)."""
+    k = kh * kw * cin
+    kp = (k + 31) // 32 * 32
+    np_ = (cout + 31) // 32 * 32
+    a = packed.reshape(kp // 4, np_, 4).transpose(0, 2, 1).reshape(kp, np_)
+    return a[:k, :cout].reshape(kh, kw, cin, cout)

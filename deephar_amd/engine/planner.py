@@ -1,0 +1,584 @@
+"""Graph -> kernel plan: fusion + lowering + activation memory planning (host logic, no GPU needed).
+
+Input: the Keras-granularity node graph of a Model (deephar_amd/graph.py).
+Output: a `Plan` = ordered list of `Step`s, one per gfx950 kernel launch through the C-ABI
+(include/deephar_hip.h), over `Value`s placed in one activation arena.
+
+Fusion rules (what the reference leaves to TensorFlow as separate kernels):
+  R1 prologue : BatchNormalization -> ReLU chains feeding a conv / depthwise conv are applied while loading
+                the conv input (layers.py:258-301 "act_conv_bn", common.py:40-54); never materialised.
+  R2 epilogue : conv -> BN -> ReLU -> add chains with a single consumer are applied on the accumulator
+                (layers.py:202-241, reception.py:57,312).
+  R3 upsample : conv -> UpSampling2D -> add (reception.py:122-127) is written by the conv epilogue at 2x
+                resolution; a free-standing UpSampling2D -> add becomes one upsample_add kernel.
+  R4 concat   : producers write straight into the concatenation buffer at their channel offset
+                (reception.py:75,83,87); Lambda channel slices are pointer/ld views (reception.py:171-172).
+  R5 decoder  : channel soft-max + both lin_interpolation_2d + joint confidence (+ global max) on the same
+                maps are one soft-argmax kernel (blocks.py:306-343).
+All tensors are fp32; sizes are tracked per batch item so one plan serves any batch size.
+"""
+import numpy as np
+
+from .. import graph as G
+
+
+class Buf:
+    def __init__(self, items, kind='act'):
+        self.items = int(items)       # floats per batch item
+        self.kind = kind              # 'act' | 'input'
+        self.start = None             # first step writing it
+        self.end = None               # last step reading/writing it
+        self.offset = None            # floats per batch item inside the arena
+        self.pinned = False           # model output: lives to the end
+
+
+class Value:
+    """A view: logical shape (batch excluded), last dim = channels with pixel stride `ld`."""
+
+    def __init__(self, shape, buf, coff=0, ld=None):
+        self.shape = tuple(shape)
+        self.buf = buf
+        self.coff = coff
+        self.ld = self.shape[-1] if ld is None else ld
+
+    @property
+    def C(self):
+        return self.shape[-1]
+
+    @property
+    def npix(self):
+        return int(np.prod(self.shape[:-1])) if len(self.shape) > 1 else 1
+
+    @property
+    def dense(self):
+        return self.coff == 0 and self.ld == self.C
+
+    def lead(self, nd):
+        """product of the dims in front of the last `nd` dims (folded into the batch)."""
+        return int(np.prod(self.shape[:-nd])) if len(self.shape) > nd else 1
+
+
+class Step:
+    def __init__(self, kind, ins, outs, attrs=None, params=None, name=None):
+        self.kind = kind
+        self.ins = ins          # dict role -> Value
+        self.outs = outs        # dict role -> Value
+        self.attrs = attrs or {}
+        self.params = params or {}  # role -> graph.Layer / Param
+        self.name = name
+
+    def flops(self, n=1):
+        """Algorithmic FLOPs (2*MAC) for n batch items (conv/GEMM-shaped steps only)."""
+        a = self.attrs
+        if self.kind == 'conv':
+            y = self.outs['y']
+            m = y.npix // (4 if a.get('up2') else 1)
+            return 2.0 * n * m * a['K'] * a['Cout']
+        if self.kind == 'dwconv':
+            y = self.outs['y']
+            return 2.0 * n * y.npix * y.C * a['kh'] * a['kw']
+        if self.kind == 'kronecker':
+            return 2.0 * n * self.ins['x'].npix * self.ins['hm'].C * self.ins['x'].C
+        return 0.0
+
+    def bytes(self, n=1):
+        """Algorithmic HBM bytes (each operand read once, result written once)."""
+        tot = 0
+        for v in list(self.ins.values()) + list(self.outs.values()):
+            if v is not None:
+                tot += v.npix * v.C
+        return 4.0 * n * tot
+
+
+class Plan:
+    def __init__(self):
+        self.steps = []
+        self.inputs = []       # Values of the model inputs
+        self.outputs = []      # Values of the model outputs
+        self.bufs = []
+        self.arena_items = 0   # floats per batch item
+        self.params = []       # ordered unique graph.Param list
+
+    def total_flops(self, n=1):
+        return sum(s.flops(n) for s in self.steps)
+
+
+# ---------------------------------------------------------------------------------------------------------
+
+class _Lazy:
+    """A not-yet-materialised element-wise chain on top of a Value (R1)."""
+
+    def __init__(self, base, bn=None, relu=False):
+        self.base = base      # Value
+        self.bn = bn          # graph.Layer or None
+        self.relu = relu
+
+
+class Planner:
+    def __init__(self, inputs, outputs):
+        self.g_inputs = inputs
+        self.g_outputs = outputs
+        self.nodes = G.topo_nodes(outputs)
+        self.plan = Plan()
+        self.val = {}          # tensor uid -> Value | _Lazy
+        self.absorbed = set()  # node uids folded into another step
+        self.consumers = {}
+        for n in self.nodes:
+            for i, t in enumerate(n.inputs):
+                self.consumers.setdefault(t.uid, []).append((n, i))
+        self.out_uids = {}
+        for t in outputs:
+            self.out_uids[t.uid] = self.out_uids.get(t.uid, 0) + 1
+        self.concat_val = {}   # concat node uid -> Value
+        self.processed = set()
+
+    # ---- helpers ------------------------------------------------------------------------------------
+    def new_buf(self, shape, kind='act'):
+        items = int(np.prod(shape))
+        items = (items + 3) // 4 * 4
+        b = Buf(items, kind)
+        self.plan.bufs.append(b)
+        return b
+
+    def new_value(self, shape):
+        return Value(shape, self.new_buf(shape))
+
+    def n_consumers(self, t):
+        return len(self.consumers.get(t.uid, [])) + self.out_uids.get(t.uid, 0)
+
+    def sole_consumer(self, t, op=None):
+        """The single consumer node of t (None if several, or t is a model output)."""
+        if self.out_uids.get(t.uid, 0):
+            return None
+        cs = self.consumers.get(t.uid, [])
+        if len(cs) != 1:
+            return None
+        n = cs[0][0]
+        if op is not None and n.op != op:
+            return None
+        return n
+
+    def emit(self, kind, ins, outs, attrs=None, params=None, name=None):
+        s = Step(kind, ins, outs, attrs, params, name)
+        self.plan.steps.append(s)
+        return s
+
+    def available(self, t):
+        return t.uid in self.val
+
+    def materialize(self, t):
+        """Value for tensor t, running a pending element-wise chain if needed."""
+        v = self.val[t.uid]
+        if isinstance(v, _Lazy):
+            out = self.new_value(v.base.shape)
+            self.emit('eltwise', dict(a=v.base), dict(y=out), dict(op=0, relu=int(v.relu)),
+                      dict(bn=v.bn) if v.bn is not None else {}, name='materialize')
+            self.val[t.uid] = out
+            return out
+        return v
+
+    def lazy_or_value(self, t):
+        return self.val[t.uid]
+
+    def out_value_for(self, t, shape=None):
+        """Where the producer of t should write: inside a concat buffer if t's only consumer is a concat."""
+        shape = shape or t.shape
+        cat = self.sole_consumer(t, 'concat')
+        if cat is not None and all(len(x.shape) == len(shape) for x in cat.inputs):
+            cv = self.concat_val.get(cat.uid)
+            if cv is None:
+                target = self.out_value_for(cat.outputs[0])
+                cv = target
+                self.concat_val[cat.uid] = cv
+            off = 0
+            for x in cat.inputs:
+                if x.uid == t.uid:
+                    break
+                off += x.shape[-1]
+            # the same tensor listed twice in one concat cannot be a view
+            if sum(1 for x in cat.inputs if x.uid == t.uid) == 1:
+                return Value(shape, cv.buf, cv.coff + off, cv.ld)
+        return self.new_value(shape)
+
+    # ---- main loop ------------------------------------------------------------------------------------
+    def run(self):
+        for t in self.g_inputs:
+            v = Value(t.shape, self.new_buf(t.shape, 'input'))
+            self.val[t.uid] = v
+            self.plan.inputs.append(v)
+        for node in self.nodes:
+            if node.uid in self.absorbed:
+                continue
+            getattr(self, 'op_' + node.op)(node)
+            self.processed.add(node.uid)
+        for t in self.g_outputs:
+            v = self.materialize(t)
+            v.buf.pinned = True
+            self.plan.outputs.append(v)
+        self._collect_params()
+        self._lifetimes()
+        self._allocate()
+        return self.plan
+
+    # ---- element-wise laziness (R1) --------------------------------------------------------------------
+    def op_bn(self, node):
+        src = self.val[node.inputs[0].uid]
+        if isinstance(src, _Lazy):
+            src = self.materialize(node.inputs[0])
+        self.val[node.outputs[0].uid] = _Lazy(src, bn=node.layers['bn'], relu=False)
+
+    def op_relu(self, node):
+        src = self.val[node.inputs[0].uid]
+        if isinstance(src, _Lazy):
+            if src.relu:
+                self.val[node.outputs[0].uid] = src
+            else:
+                self.val[node.outputs[0].uid] = _Lazy(src.base, bn=src.bn, relu=True)
+        else:
+            self.val[node.outputs[0].uid] = _Lazy(src, relu=True)
+
+    # ---- convolutions ------------------------------------------------------------------------------------
+    def _prologue(self, t):
+        v = self.val[t.uid]
+        if isinstance(v, _Lazy):
+            return v.base, v.bn, v.relu
+        return v, None, False
+
+    def _epilogue(self, out_t):
+        """Walk conv -> bn -> relu -> add -> (upsample -> add) while each link has a single consumer."""
+        epi = dict(post_bn=None, post_relu=False, res1=None, res2=None, up2=False)
+        t = out_t
+        n = self.sole_consumer(t, 'bn')
+        if n is not None:
+            epi['post_bn'] = n.layers['bn']
+            self.absorbed.add(n.uid)
+            t = n.outputs[0]
+        n = self.sole_consumer(t, 'relu')
+        if n is not None:
+            epi['post_relu'] = True
+            self.absorbed.add(n.uid)
+            t = n.outputs[0]
+        if not epi['post_relu']:
+            n = self.sole_consumer(t, 'add')
+            if n is not None:
+                others = [x for x in n.inputs if x.uid != t.uid]
+                if len(others) == len(n.inputs) - 1 and 1 <= len(others) <= 2 and \
+                        all(self.available(x) for x in others):
+                    vals = [self.materialize(x) for x in others]
+                    epi['res1'] = vals[0]
+                    if len(vals) > 1:
+                        epi['res2'] = vals[1]
+                    self.absorbed.add(n.uid)
+                    t = n.outputs[0]
+            if epi['res2'] is None:
+                u = self.sole_consumer(t, 'upsample')
+                if u is not None and len(t.shape) >= 3:
+                    a = self.sole_consumer(u.outputs[0], 'add')
+                    if a is not None and len(a.inputs) == 2:
+                        other = [x for x in a.inputs if x.uid != u.outputs[0].uid]
+                        if len(other) == 1 and self.available(other[0]):
+                            epi['res2'] = self.materialize(other[0])
+                            epi['up2'] = True
+                            self.absorbed.add(u.uid)
+                            self.absorbed.add(a.uid)
+                            t = a.outputs[0]
+        return epi, t
+
+    def _emit_conv(self, x, pre_bn, pre_relu, param, a, out_t, name):
+        epi, final_t = self._epilogue(out_t)
+        y = self.out_value_for(final_t)
+        attrs = dict(kh=a['kh'], kw=a['kw'], sh=a.get('sh', 1), sw=a.get('sw', 1), pt=a['pt'], pl=a['pl'],
+                     Cin=x.C, Cout=a['filters'], K=a['kh'] * a['kw'] * x.C, pre_relu=int(pre_relu),
+                     post_relu=int(epi['post_relu']), up2=int(epi['up2']))
+        ins = dict(x=x)
+        if epi['res1'] is not None:
+            ins['res1'] = epi['res1']
+        if epi['res2'] is not None:
+            ins['res2'] = epi['res2']
+        params = dict(w=param)
+        if pre_bn is not None:
+            params['pre_bn'] = pre_bn
+        if epi['post_bn'] is not None:
+            params['post_bn'] = epi['post_bn']
+        self.emit('conv', ins, dict(y=y), attrs, params, name)
+        self.val[final_t.uid] = y
+
+    def op_conv(self, node):
+        x, pre_bn, pre_relu = self._prologue(node.inputs[0])
+        self._emit_conv(x, pre_bn, pre_relu, node.layers['conv'].params[0], node.attrs, node.outputs[0],
+                        node.name)
+
+    def op_sepconv(self, node):
+        x, pre_bn, pre_relu = self._prologue(node.inputs[0])
+        layer = node.layers['sepconv']
+        a = node.attrs
+        mid = self.new_value(node.inputs[0].shape)
+        params = dict(w=layer.params[0])
+        if pre_bn is not None:
+            params['pre_bn'] = pre_bn
+        self.emit('dwconv', dict(x=x), dict(y=mid),
+                  dict(kh=a['kh'], kw=a['kw'], pt=a['pt'], pl=a['pl'], pre_relu=int(pre_relu)), params,
+                  node.name + '/dw')
+        pw = dict(kh=1, kw=1, sh=1, sw=1, pt=0, pl=0, filters=a['filters'])
+        self._emit_conv(mid, None, False, layer.params[1], pw, node.outputs[0], node.name + '/pw')
+
+    # ---- glue ------------------------------------------------------------------------------------------
+    def op_add(self, node):
+        vals = [self.materialize(t) for t in node.inputs]
+        y = self.out_value_for(node.outputs[0])
+        acc = vals[0]
+        rest = vals[1:]
+        while rest:
+            chunk, rest = rest[:2], rest[2:]
+            dst = y if not rest else self.new_value(node.outputs[0].shape)
+            ins = dict(a=acc, b=chunk[0])
+            if len(chunk) > 1:
+                ins['c'] = chunk[1]
+            self.emit('eltwise', ins, dict(y=dst), dict(op=0, relu=0), name=node.name or 'add')
+            acc = dst
+        self.val[node.outputs[0].uid] = y
+
+    def op_mul(self, node):
+        a = self.materialize(node.inputs[0])
+        b = self.materialize(node.inputs[1])
+        y = self.out_value_for(node.outputs[0])
+        self.emit('eltwise', dict(a=a, b=b), dict(y=y), dict(op=1, relu=0, bcast_b=int(b.C == 1 and a.C != 1)),
+                  name=node.name or 'mul')
+        self.val[node.outputs[0].uid] = y
+
+    def op_sigmoid(self, node):
+        a = self.materialize(node.inputs[0])
+        y = self.out_value_for(node.outputs[0])
+        self.emit('eltwise', dict(a=a), dict(y=y), dict(op=2, relu=0), name=node.name or 'sigmoid')
+        self.val[node.outputs[0].uid] = y
+
+    def op_concat(self, node):
+        cv = self.concat_val.get(node.uid)
+        if cv is None:
+            cv = self.out_value_for(node.outputs[0])
+            self.concat_val[node.uid] = cv
+        off = 0
+        for t in node.inputs:
+            v = self.materialize(t)
+            c = t.shape[-1]
+            if not (v.buf is cv.buf and v.coff == cv.coff + off and v.ld == cv.ld):
+                dst = Value(t.shape, cv.buf, cv.coff + off, cv.ld)
+                self.emit('copy', dict(x=v), dict(y=dst), name=node.name or 'concat')
+            off += c
+        self.val[node.outputs[0].uid] = cv
+
+    def op_slice(self, node):
+        v = self.materialize(node.inputs[0])
+        a = node.attrs
+        self.val[node.outputs[0].uid] = Value(node.outputs[0].shape, v.buf, v.coff + a['start'], v.ld)
+
+    def op_reshape(self, node):
+        v = self.materialize(node.inputs[0])
+        shape = node.outputs[0].shape
+        if not v.dense:
+            # e.g. [.., C, 1] view of a [.., C] slab living inside a concat buffer: keep ld if only the
+            # trailing unit dim changes, else copy to a dense buffer first
+            if shape[-1] == 1 and tuple(shape[:-1]) == tuple(v.shape) and False:
+                pass
+            d = self.new_value(v.shape)
+            self.emit('copy', dict(x=v), dict(y=d), name='densify')
+            v = d
+        self.val[node.outputs[0].uid] = Value(shape, v.buf, 0, shape[-1])
+
+    def op_pool(self, node):
+        x = self.materialize(node.inputs[0])
+        y = self.out_value_for(node.outputs[0])
+        self.emit('pool', dict(x=x), dict(y=y), dict(node.attrs), name=node.name or 'pool')
+        self.val[node.outputs[0].uid] = y
+
+    def op_upsample(self, node):
+        b = self.materialize(node.inputs[0])
+        t = node.outputs[0]
+        a_node = self.sole_consumer(t, 'add')
+        if a_node is not None and len(a_node.inputs) == 2:
+            other = [x for x in a_node.inputs if x.uid != t.uid]
+            if len(other) == 1 and self.available(other[0]):
+                a = self.materialize(other[0])
+                y = self.out_value_for(a_node.outputs[0])
+                self.emit('upsample_add', dict(a=a, b=b), dict(y=y), name='upsample_add')
+                self.absorbed.add(a_node.uid)
+                self.val[a_node.outputs[0].uid] = y
+                return
+        y = self.out_value_for(t)
+        self.emit('upsample_add', dict(b=b), dict(y=y), name='upsample')
+        self.val[t.uid] = y
+
+    def op_zeropad(self, node):
+        x = self.materialize(node.inputs[0])
+        if not x.dense:
+            d = self.new_value(x.shape)
+            self.emit('copy', dict(x=x), dict(y=d), name='densify')
+            x = d
+        y = self.new_value(node.outputs[0].shape)
+        self.emit('zeropad', dict(x=x), dict(y=y), name=node.name or 'zeropad')
+        self.val[node.outputs[0].uid] = y
+
+    # ---- decoder (R5) ------------------------------------------------------------------------------------
+    def _sam(self, h_t, alpha, softmax_node):
+        """One soft-argmax kernel covering every decoder read-out of the maps `h_t`."""
+        h = self.materialize(h_t)
+        outs, attrs = {}, dict(alpha=float(alpha), conf_scale=1.0)
+        if softmax_node is not None:
+            p_t = softmax_node.outputs[0]
+            need_prob = bool(self.out_uids.get(p_t.uid, 0))
+            for n, _ in self.consumers.get(p_t.uid, []):
+                if n.op == 'expect2d' and 'xy' not in outs:
+                    outs['xy'] = self.out_value_for(n.outputs[0])
+                    self.val[n.outputs[0].uid] = outs['xy']
+                    self.absorbed.add(n.uid)
+                elif n.op == 'jointprob' and 'conf_prob' not in outs and n.attrs.get('scale', 1.0) == 1.0:
+                    outs['conf_prob'] = self.out_value_for(n.outputs[0])
+                    self.val[n.outputs[0].uid] = outs['conf_prob']
+                    self.absorbed.add(n.uid)
+                else:
+                    need_prob = True
+            if need_prob:
+                outs['prob'] = self.out_value_for(p_t)
+                self.val[p_t.uid] = outs['prob']
+            else:
+                self.val[p_t.uid] = None  # never read
+        # siblings reading the raw maps
+        for n, _ in self.consumers.get(h_t.uid, []):
+            if n.uid in self.absorbed or n.uid in self.processed or n is softmax_node:
+                continue
+            if n.op == 'jointprob' and 'conf_raw' not in outs:
+                outs['conf_raw'] = self.out_value_for(n.outputs[0])
+                attrs['conf_scale'] = float(n.attrs.get('scale', 1.0))
+                self.val[n.outputs[0].uid] = outs['conf_raw']
+                self.absorbed.add(n.uid)
+            elif n.op == 'globalmax2d' and 'gmax' not in outs:
+                outs['gmax'] = self.new_value(n.outputs[0].shape)
+                self.val[n.outputs[0].uid] = outs['gmax']
+                self.absorbed.add(n.uid)
+        self.emit('sam', dict(h=h), outs, attrs, name='softargmax2d')
+
+    def op_softmax2d(self, node):
+        self._sam(node.inputs[0], node.attrs['alpha'], node)
+
+    def op_jointprob(self, node):
+        # not claimed by a sibling soft-max: stand-alone confidence read-out
+        h = self.materialize(node.inputs[0])
+        y = self.out_value_for(node.outputs[0])
+        self.emit('sam', dict(h=h), dict(conf_raw=y), dict(alpha=1.0, conf_scale=float(node.attrs['scale'])),
+                  name='jointprob')
+        self.val[node.outputs[0].uid] = y
+
+    def op_globalmax2d(self, node):
+        h = self.materialize(node.inputs[0])
+        y = self.new_value(node.outputs[0].shape)
+        self.emit('sam', dict(h=h), dict(gmax=y), dict(alpha=1.0, conf_scale=1.0), name='globalmax2d')
+        self.val[node.outputs[0].uid] = y
+
+    def op_expect2d(self, node):
+        raise NotImplementedError('softargmax2d must be applied to the output of act_channel_softmax')
+
+    def op_context_agg(self, node):
+        ys, yc, pc = [self.materialize(t) for t in node.inputs]
+        for v in (ys, yc, pc):
+            assert v.dense, 'context aggregation expects dense operands'
+        y = self.out_value_for(node.outputs[0])
+        self.emit('context_agg', dict(ys=ys, yc=yc, pc=pc), dict(y=y), dict(node.attrs), name=node.name)
+        self.val[node.outputs[0].uid] = y
+
+    def op_depthmean(self, node):
+        h = self.materialize(node.inputs[0])
+        y = self.new_value(node.outputs[0].shape)
+        role = 'hxy' if node.attrs['axis'] == 'd' else 'hz'
+        self.emit('depth_means', dict(h=h), {role: y}, dict(D=node.attrs['D'], J=node.attrs['J']),
+                  name='depth_means_' + role)
+        self.val[node.outputs[0].uid] = y
+
+    def op_softargmax1d(self, node):
+        hz = self.materialize(node.inputs[0])
+        assert hz.dense
+        outs = dict(z=self.out_value_for(node.outputs[0]))
+        for n, _ in self.consumers.get(node.inputs[0].uid, []):
+            if n.op == 'globalmax1d' and n.uid not in self.absorbed and n.uid not in self.processed:
+                outs['vz'] = self.new_value(n.outputs[0].shape)
+                self.val[n.outputs[0].uid] = outs['vz']
+                self.absorbed.add(n.uid)
+                break
+        self.emit('softargmax1d', dict(hz=hz), outs, name='softargmax1d')
+        self.val[node.outputs[0].uid] = outs['z']
+
+    def op_globalmax1d(self, node):
+        hz = self.materialize(node.inputs[0])
+        y = self.new_value(node.outputs[0].shape)
+        self.emit('softargmax1d', dict(hz=hz), dict(vz=y), name='globalmax1d')
+        self.val[node.outputs[0].uid] = y
+
+    def op_kronecker(self, node):
+        hm = self.materialize(node.inputs[0])
+        x = self.materialize(node.inputs[1])
+        y = self.out_value_for(node.outputs[0])
+        self.emit('kronecker', dict(hm=hm, x=x), dict(y=y), name=node.name or 'kronecker')
+        self.val[node.outputs[0].uid] = y
+
+    def op_globalmaxmin(self, node):
+        x = self.materialize(node.inputs[0])
+        t = node.outputs[0]
+        sm = self.sole_consumer(t, 'softmax')
+        final = sm.outputs[0] if sm is not None else t
+        if sm is not None:
+            self.absorbed.add(sm.uid)
+        y = self.new_value(final.shape)
+        self.emit('globalmaxmin', dict(x=x), dict(y=y), dict(softmax=int(sm is not None)), name=node.name)
+        self.val[final.uid] = y
+
+    def op_softmax(self, node):
+        raise NotImplementedError('stand-alone softmax (only used after global_max_min_pooling)')
+
+    # ---- bookkeeping ------------------------------------------------------------------------------------
+    def _collect_params(self):
+        seen, out = set(), []
+        for n in self.nodes:
+            for layer in n.layers.values():
+                for p in layer.params:
+                    if id(p) not in seen:
+                        seen.add(id(p))
+                        out.append(p)
+        self.plan.params = out
+
+    def _lifetimes(self):
+        for i, s in enumerate(self.plan.steps):
+            for v in list(s.ins.values()) + list(s.outs.values()):
+                if v is None:
+                    continue
+                b = v.buf
+                if b.start is None:
+                    b.start = i
+                b.end = i
+        last = len(self.plan.steps)
+        for b in self.plan.bufs:
+            if b.kind == 'input':
+                b.start = -1
+                if b.end is None:
+                    b.end = -1
+            if b.start is None:          # never touched (e.g. an output that is an input)
+                b.start, b.end = 0, last
+            if b.pinned:
+                b.end = last
+
+    def _allocate(self):
+        """Offline interval packing: largest buffers first, lowest non-conflicting offset."""
+        placed = []
+        for b in sorted(self.plan.bufs, key=lambda b: -b.items):
+            conflicts = sorted((p.offset, p.offset + p.items) for p in placed
+                               if not (p.end < b.start or b.end < p.start))
+            off = 0
+            for lo, hi in conflicts:
+                if off + b.items <= lo:
+                    break
+                off = max(off, hi)
+            b.offset = off
+            placed.append(b)
+        self.plan.arena_items = max((b.offset + b.items for b in self.plan.bufs), default=0)
+
+
+def build_plan(inputs, outputs):
+    return Planner(inputs, outputs).run()

@@ -1,0 +1,206 @@
+"""Op-level Python API over the C-ABI, on torch CUDA tensors (NHWC fp32, contiguous).
+
+One function per kernel entry point of include/deephar_hip.h; used by the op parity tests and available to
+callers that want a single fused op rather than a whole Model.  Launches go to torch's current stream.
+No CPU path: every function raises if handed a non-CUDA tensor.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from .engine import packing
+from .engine.executor import grid_x, grid_depth
+from .layers import same_pad
+
+
+def _t():
+    import torch
+    return torch
+
+
+def _stream():
+    return _t().cuda.current_stream().cuda_stream
+
+
+def _chk(*tensors):
+    torch = _t()
+    for t in tensors:
+        if t is None:
+            continue
+        if not (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()):
+            raise ValueError('deephar_amd.functional expects contiguous float32 CUDA tensors')
+
+
+def _p(t):
+    return t.data_ptr() if t is not None else None
+
+
+def pack_conv_weight(w_hwio, device='cuda'):
+    """HWIO numpy kernel -> (packed device tensor, Kp, Np)."""
+    torch = _t()
+    packed, kp, np_ = packing.pack_conv(np.asarray(w_hwio, np.float32))
+    return torch.from_numpy(packed).to(device), kp, np_
+
+
+def conv2d(x, w_hwio, strides=(1, 1), padding='same', pre_scale=None, pre_shift=None, pre_relu=False,
+           post_scale=None, post_shift=None, post_relu=False, res1=None, res2=None, up2=False, tile_cfg=-1,
+           packed=None):
+    """Fused conv (see dh_conv2d_f32).  x [N,H,W,Cin]; w_hwio numpy [kh,kw,Cin,Cout]."""
+    torch = _t()
+    _chk(x, pre_scale, pre_shift, post_scale, post_shift, res1, res2)
+    lib = _lib.load()
+    kh, kw, cin, cout = w_hwio.shape
+    n, h, w_, c = x.shape
+    assert c == cin
+    if padding == 'same':
+        pt, _, oh = same_pad(h, kh, strides[0])
+        pl, _, ow = same_pad(w_, kw, strides[1])
+    else:
+        pt = pl = 0
+        oh, ow = (h - kh) // strides[0] + 1, (w_ - kw) // strides[1] + 1
+    wt, kp, np_ = packed if packed is not None else pack_conv_weight(w_hwio, x.device)
+    up = 2 if up2 else 1
+    y = torch.empty((n, oh * up, ow * up, cout), dtype=torch.float32, device=x.device)
+    a = _lib.ConvArgs()
+    a.x, a.w, a.y = _p(x), _p(wt), _p(y)
+    a.pre_scale, a.pre_shift, a.post_scale, a.post_shift = _p(pre_scale), _p(pre_shift), _p(post_scale), _p(post_shift)
+    a.res1, a.res2 = _p(res1), _p(res2)
+    a.N, a.H, a.W, a.Cin, a.ldx = n, h, w_, cin, cin
+    a.OH, a.OW, a.Cout, a.ldy = oh, ow, cout, cout
+    a.KH, a.KW, a.SH, a.SW, a.PT, a.PL = kh, kw, strides[0], strides[1], pt, pl
+    a.K, a.Kp, a.Np = kh * kw * cin, kp, np_
+    a.ldr1 = res1.shape[-1] if res1 is not None else 0
+    a.ldr2 = res2.shape[-1] if res2 is not None else 0
+    a.pre_relu, a.post_relu, a.up2 = int(pre_relu), int(post_relu), int(up2)
+    _lib.check(lib.dh_conv2d_f32(C.byref(a), tile_cfg, _stream()), 'dh_conv2d_f32')
+    return y
+
+
+def dwconv2d(x, dw_kernel, pre_scale=None, pre_shift=None, pre_relu=False):
+    """Depthwise conv, stride 1, TF-SAME.  dw_kernel numpy [kh,kw,C,1]."""
+    torch = _t()
+    _chk(x, pre_scale, pre_shift)
+    lib = _lib.load()
+    kh, kw, c, _ = dw_kernel.shape
+    n, h, w_, cx = x.shape
+    assert cx == c
+    pt, _, _ = same_pad(h, kh, 1)
+    pl, _, _ = same_pad(w_, kw, 1)
+    wt = torch.from_numpy(np.ascontiguousarray(dw_kernel.reshape(kh * kw, c), np.float32)).to(x.device)
+    y = torch.empty_like(x)
+    a = _lib.DwArgs()
+    a.x, a.w, a.y, a.pre_scale, a.pre_shift = _p(x), _p(wt), _p(y), _p(pre_scale), _p(pre_shift)
+    a.N, a.H, a.W, a.C, a.ldx, a.ldy = n, h, w_, c, c, c
+    a.KH, a.KW, a.PT, a.PL, a.pre_relu = kh, kw, pt, pl, int(pre_relu)
+    _lib.check(lib.dh_dwconv2d_f32(C.byref(a), _stream()), 'dh_dwconv2d_f32')
+    return y
+
+
+def pool2d(x, pool=(2, 2), strides=None, padding='valid', mode=0):
+    torch = _t()
+    _chk(x)
+    lib = _lib.load()
+    strides = strides or pool
+    n, h, w_, c = x.shape
+    if padding == 'same':
+        pt, _, oh = same_pad(h, pool[0], strides[0])
+        pl, _, ow = same_pad(w_, pool[1], strides[1])
+    else:
+        pt = pl = 0
+        oh, ow = (h - pool[0]) // strides[0] + 1, (w_ - pool[1]) // strides[1] + 1
+    y = torch.empty((n, oh, ow, c), dtype=torch.float32, device=x.device)
+    a = _lib.PoolArgs()
+    a.x, a.y = _p(x), _p(y)
+    a.N, a.H, a.W, a.C, a.ldx, a.OH, a.OW, a.ldy = n, h, w_, c, c, oh, ow, c
+    a.KH, a.KW, a.SH, a.SW, a.PT, a.PL, a.mode = pool[0], pool[1], strides[0], strides[1], pt, pl, mode
+    _lib.check(lib.dh_pool2d_f32(C.byref(a), _stream()), 'dh_pool2d_f32')
+    return y
+
+
+def upsample2x_add(b, a=None):
+    torch = _t()
+    _chk(a, b)
+    n, h, w_, c = b.shape
+    y = torch.empty((n, 2 * h, 2 * w_, c), dtype=torch.float32, device=b.device)
+    _lib.check(_lib.load().dh_upsample2x_add_f32(_p(a), c, _p(b), c, _p(y), c, n, 2 * h, 2 * w_, c, _stream()),
+               'dh_upsample2x_add_f32')
+    return y
+
+
+def softargmax2d(h, alpha=1.0, conf_scale=1.0, want_prob=False):
+    """Returns dict(xy [F,C,2], conf_raw [F,C,1], conf_prob [F,C,1], gmax [F,C], prob [F,H,W,C] | None)."""
+    torch = _t()
+    _chk(h)
+    f, hh, ww, c = h.shape
+    dev = h.device
+    out = dict(xy=torch.empty((f, c, 2), device=dev), conf_raw=torch.empty((f, c, 1), device=dev),
+               conf_prob=torch.empty((f, c, 1), device=dev), gmax=torch.empty((f, c), device=dev),
+               prob=torch.empty_like(h) if want_prob else None)
+    gx = torch.from_numpy(grid_x(ww)).to(dev)
+    gy = torch.from_numpy(grid_x(hh)).to(dev)
+    a = _lib.SamArgs()
+    a.h, a.gx, a.gy = _p(h), _p(gx), _p(gy)
+    a.xy, a.conf_raw, a.conf_prob, a.prob, a.gmax = (_p(out['xy']), _p(out['conf_raw']), _p(out['conf_prob']),
+                                                     _p(out['prob']), _p(out['gmax']))
+    a.F, a.H, a.W, a.C, a.ldh, a.ldxy, a.ldcr, a.ldcp, a.ldp = f, hh, ww, c, c, 2, 1, 1, c
+    a.alpha, a.conf_scale = float(alpha), float(conf_scale)
+    _lib.check(_lib.load().dh_softargmax2d_f32(C.byref(a), _stream()), 'dh_softargmax2d_f32')
+    torch.cuda.current_stream().synchronize()  # gx/gy are temporaries
+    return out
+
+
+def context_aggregation(ys, yc, pc, num_context, alpha):
+    torch = _t()
+    _chk(ys, yc, pc)
+    f, j, _ = ys.shape
+    y = torch.empty_like(ys)
+    _lib.check(_lib.load().dh_context_aggregation_f32(_p(ys), _p(yc), _p(pc), _p(y), f, j, num_context,
+                                                      float(alpha), 2, _stream()), 'dh_context_aggregation_f32')
+    return y
+
+
+def depth_means(h, depth, joints):
+    torch = _t()
+    _chk(h)
+    f, hh, ww, c = h.shape
+    assert c == depth * joints
+    hxy = torch.empty((f, hh, ww, joints), device=h.device)
+    hz = torch.empty((f, depth, joints), device=h.device)
+    _lib.check(_lib.load().dh_depth_means_f32(_p(h), c, _p(hxy), _p(hz), f, hh * ww, depth, joints, _stream()),
+               'dh_depth_means_f32')
+    return hxy, hz
+
+
+def softargmax1d(hz):
+    torch = _t()
+    _chk(hz)
+    f, d, j = hz.shape
+    z = torch.empty((f, j, 1), device=hz.device)
+    vz = torch.empty((f, j), device=hz.device)
+    grid = torch.from_numpy(grid_depth(d)).to(hz.device)
+    _lib.check(_lib.load().dh_softargmax1d_f32(_p(hz), _p(grid), _p(z), 1, _p(vz), f, d, j, _stream()),
+               'dh_softargmax1d_f32')
+    torch.cuda.current_stream().synchronize()
+    return z, vz
+
+
+def kronecker(hm, x):
+    torch = _t()
+    _chk(hm, x)
+    b, hh, ww, j = hm.shape
+    c = x.shape[-1]
+    f = torch.empty((b, j, c), device=hm.device)
+    _lib.check(_lib.load().dh_kronecker_f32(_p(hm), j, _p(x), c, _p(f), c, b, hh * ww, j, c, _stream()),
+               'dh_kronecker_f32')
+    return f
+
+
+def global_maxmin_softmax(x, softmax=True):
+    torch = _t()
+    _chk(x)
+    b, t, j, c = x.shape
+    y = torch.empty((b, c), device=x.device)
+    _lib.check(_lib.load().dh_global_maxmin_softmax_f32(_p(x), c, _p(y), b, t * j, c, int(softmax), _stream()),
+               'dh_global_maxmin_softmax_f32')
+    return y

@@ -1,0 +1,194 @@
+"""`Model`: the Keras-Model-shaped object the reference's callers hold.
+
+Surface used by exp/ and exp/common/*_tools.py and reproduced here with the same meaning:
+  predict(x, batch_size=32, verbose=0)   mpii_tools.py:25,56,86  h36m_tools.py:46  penn_tools.py:18,55,124
+  load_weights(path, by_name=False)      eval_mpii_singleperson.py:54, eval_penn_multitask.py:76
+  outputs / output / input / inputs      eval_mpii_singleperson.py:56-61, eval_speed2d.py:62-68
+  input_shape, get_input_shape_at(0)     h36m_tools.py:20, mpii_tools.py:67
+  get_layer(name), layers, name, summary action.py:117-179
+  __call__(tensor)                        nested models: reception.py:93,131; action.py:124-125,357,366
+Execution is the gfx950 engine (deephar_amd/engine); there is no CPU execution path.
+"""
+import numpy as np
+
+from . import graph as G
+
+
+class Model:
+    def __init__(self, inputs, outputs, name=None):
+        self._single_in = not isinstance(inputs, (list, tuple))
+        self._single_out = not isinstance(outputs, (list, tuple))
+        self.inputs = [inputs] if self._single_in else list(inputs)
+        self.outputs = [outputs] if self._single_out else list(outputs)
+        for t in self.inputs + self.outputs:
+            if not isinstance(t, G.Tensor):
+                raise TypeError('Model inputs/outputs must be symbolic tensors, got %r' % (t,))
+        self.name = name or 'model_%d' % next(G._uid)
+        self.trainable = True
+        self._plan = None
+        self._exec = None
+        # validates connectivity early (raises like Keras' "graph disconnected")
+        self._nodes = G.topo_nodes(self.outputs)
+        reach = {t.uid for t in self.inputs}
+        for n in self._nodes:
+            for t in n.inputs:
+                if t.uid not in reach:
+                    raise ValueError('Graph disconnected: %r is not derived from the model inputs' % t)
+            for o in n.outputs:
+                reach.add(o.uid)
+
+    # ---- Keras-like attributes -----------------------------------------------------------------------
+    @property
+    def input(self):
+        return self.inputs[0] if len(self.inputs) == 1 else self.inputs
+
+    @property
+    def output(self):
+        return self.outputs[0] if len(self.outputs) == 1 else self.outputs
+
+    @property
+    def input_shape(self):
+        shapes = [(None,) + t.shape for t in self.inputs]
+        return shapes[0] if len(shapes) == 1 else shapes
+
+    @property
+    def output_shape(self):
+        shapes = [(None,) + t.shape for t in self.outputs]
+        return shapes[0] if len(shapes) == 1 else shapes
+
+    def get_input_shape_at(self, index):
+        if index != 0:
+            raise ValueError('only node index 0 exists')
+        return self.input_shape
+
+    @property
+    def layers(self):
+        """Top-level layers in graph order: nested Models (by call) and weight-owning layers."""
+        seen, out = set(), []
+        for n in self._nodes:
+            path = n.attrs.get('_models')
+            objs = [path[0]] if path else list(n.layers.values())
+            for o in objs:
+                if id(o) not in seen:
+                    seen.add(id(o))
+                    out.append(o)
+        return out
+
+    def get_layer(self, name=None, index=None):
+        if index is not None:
+            return self.layers[index]
+        for l in self.layers:
+            if l.name == name:
+                return l
+        raise ValueError('No such layer: %s' % name)
+
+    @property
+    def params(self):
+        seen, out = set(), []
+        for n in self._nodes:
+            for layer in n.layers.values():
+                for p in layer.params:
+                    if id(p) not in seen:
+                        seen.add(id(p))
+                        out.append(p)
+        return out
+
+    @property
+    def weights(self):
+        return self.params
+
+    def count_params(self):
+        return int(sum(np.prod(p.shape) for p in self.params))
+
+    def get_weights(self):
+        return [p.value for p in self.params]
+
+    def set_weights(self, values):
+        ps = self.params
+        if len(values) != len(ps):
+            raise ValueError('model %s expects %d weight arrays, got %d' % (self.name, len(ps), len(values)))
+        for p, v in zip(ps, values):
+            p.set(v)
+
+    def summary(self, print_fn=print):
+        print_fn('Model "%s": %d graph nodes, %d parameters' % (self.name, len(self._nodes), self.count_params()))
+        for l in self.layers:
+            if isinstance(l, Model):
+                print_fn('  %-28s Model   %10d params' % (l.name, l.count_params()))
+            else:
+                print_fn('  %-28s %-18s %s' % (l.name, l.cls, [p.shape for p in l.params]))
+
+    # ---- functional call (nested model) --------------------------------------------------------------
+    def __call__(self, x):
+        xs = list(x) if isinstance(x, (list, tuple)) else [x]
+        outs = G.clone_subgraph(self.inputs, self.outputs, xs)
+        tagged = set()
+        stack = [t.node for t in outs if t.node is not None]
+        stop = {t.uid for t in xs}
+        while stack:
+            n = stack.pop()
+            if n.uid in tagged:
+                continue
+            tagged.add(n.uid)
+            n.attrs['_models'] = [self] + list(n.attrs.get('_models', []))
+            for t in n.inputs:
+                if t.uid not in stop and t.node is not None:
+                    stack.append(t.node)
+        return outs[0] if self._single_out else outs
+
+    # ---- weights I/O -------------------------------------------------------------------------------------
+    def load_weights(self, filepath, by_name=False):
+        from . import weights as W
+        W.load_weights(self, filepath, by_name=by_name)
+        if self._exec is not None:
+            self._exec.refresh_weights()
+
+    def save_weights(self, filepath):
+        from . import weights as W
+        W.save_weights(self, filepath)
+
+    # ---- execution -----------------------------------------------------------------------------------------
+    @property
+    def plan(self):
+        if self._plan is None:
+            from .engine.planner import build_plan
+            self._plan = build_plan(self.inputs, self.outputs)
+        return self._plan
+
+    @property
+    def executor(self):
+        if self._exec is None:
+            from .engine.executor import Executor
+            self._exec = Executor(self.plan)
+        return self._exec
+
+    def predict(self, x, batch_size=32, verbose=0):
+        """Forward pass on the GPU in chunks of `batch_size` (keras Model.predict semantics): returns one
+        np.float32 array per model output, or a bare array when the model has a single output."""
+        xs = list(x) if isinstance(x, (list, tuple)) else [x]
+        if len(xs) != len(self.inputs):
+            raise ValueError('model %s expects %d input arrays, got %d' % (self.name, len(self.inputs), len(xs)))
+        xs = [np.asarray(a) for a in xs]
+        total = xs[0].shape[0]
+        for a, t in zip(xs, self.inputs):
+            if tuple(a.shape[1:]) != t.shape or a.shape[0] != total:
+                raise ValueError('input array has shape %s, model expects (N,)+%s' % (a.shape, t.shape))
+        ex = self.executor
+        bs = int(min(batch_size or total, total)) if total else 1
+        chunks = []
+        for i in range(0, total, bs):
+            part = [a[i:i + bs] for a in xs]
+            chunks.append(ex.run(part, n=bs))
+            if verbose:
+                print('%d/%d' % (min(i + bs, total), total))
+        if not chunks:
+            outs = [np.zeros((0,) + t.shape, np.float32) for t in self.outputs]
+        else:
+            outs = [np.concatenate([c[k] for c in chunks], axis=0) for k in range(len(self.outputs))]
+        return outs[0] if len(outs) == 1 else outs
+
+
+def concatenate(tensors, axis=-1, name=None):
+    """keras.layers.concatenate on symbolic outputs (re-wrapping idiom, eval_mpii_singleperson.py:56-61)."""
+    from . import layers
+    return layers.concatenate(tensors, axis=axis, name=name)

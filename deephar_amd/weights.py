@@ -1,0 +1,183 @@
+"""Weights: synthetic initialisation, .npz persistence, Keras-ordered import.
+
+The published Keras HDF5 weight files (exp/mpii/eval_mpii_singleperson.py:29-33 etc.) are not available
+offline and h5py is absent from the main interpreter; the native on-disk format here is
+.npz keyed by '<scope>/<layer>/<weight>'.  `load_weights` also accepts
+  * an .npz written by `tools/h5_to_npz.py` from a Keras `save_weights` file (keys 'h5:<idx>:<name>' in
+    Keras' topological weight order, or plain Keras weight names for by_name=True).
+Synthetic weights follow SURVEY.md 8d: He-normal conv kernels, randomised BN statistics, fixed seed.
+"""
+import zlib
+
+import numpy as np
+
+
+def _rng(key, seed):
+    return np.random.default_rng((zlib.crc32(key.encode()) + 7919 * seed) & 0xffffffff)
+
+
+def _relu_moments(mu, var):
+    """Mean / variance of relu(x), x ~ N(mu, var)."""
+    from math import erf, exp, pi, sqrt
+    sd = sqrt(max(var, 1e-12))
+    z = mu / sd
+    pdf = exp(-0.5 * z * z) / sqrt(2 * pi)
+    cdf = 0.5 * (1 + erf(z / sqrt(2)))
+    m1 = sd * (pdf + z * cdf)
+    m2 = var * ((1 + z * z) * cdf + z * pdf)
+    return m1, max(m2 - m1 * m1, 1e-12)
+
+
+_MAXPOOL = {1: (0.0, 1.0), 2: (0.564, 0.682), 4: (1.029, 0.492), 9: (1.485, 0.357)}  # E, Var of max of n N(0,1)
+
+
+def init_synthetic(model, seed=0, logit_std=6.0):
+    """Deterministic synthetic weights that behave like a trained network.
+
+    Conv kernels are He-normal.  BatchNormalization statistics are NOT drawn blindly: a scalar mean/variance
+    estimate is propagated through the graph (Gaussian closed forms for ReLU / max-pool, independence for
+    add) and each BN gets moving_mean/variance = the predicted statistics of its input times a per-channel
+    jitter in [0.6, 1.6], plus beta ~ N(0, 0.1) (gamma ~ U(0.8, 1.2) where present).  That keeps activations
+    O(1) through ~150 layers; blind statistics make the 8-block residual stack explode to ~1e10 and the
+    soft-max one-hot, which would make the 1e-3 px parity test vacuous.  Heat-map heads (convs without BN
+    that feed the soft-argmax decoder) are scaled so the logits have std ~= `logit_std`.
+    Every tensor is seeded by crc32(key) ^ seed, independent of creation order.
+    """
+    est = {}
+    for t in model.inputs:
+        est[t.uid] = (0.0, 1.0 / 3.0)  # inputs are U(-1, 1) (utils/transform.py:212-231 range)
+
+    consumers = {}
+    for n in model._nodes:
+        for t in n.inputs:
+            consumers.setdefault(t.uid, []).append(n)
+
+    def feeds_decoder(t, depth=0):
+        """(True, D) if tensor t reaches a channel soft-max through slices / depth means only."""
+        for c in consumers.get(t.uid, []):
+            if c.op == 'softmax2d':
+                return True, 1
+            if c.op in ('slice', 'depthmean'):
+                ok, d = feeds_decoder(c.outputs[0], depth + 1)
+                if ok:
+                    return True, d * (c.attrs['D'] if c.op == 'depthmean' and c.attrs['axis'] == 'd' else 1)
+        return False, 1
+
+    def set_conv(p, k, gain, m2_in, head_offset=None):
+        if p.value is None or p.version == 0 or getattr(p, '_synth_seed', None) != seed:
+            w = _rng(p.key, seed).standard_normal(p.shape) * np.sqrt(gain / k)
+            if head_offset is not None:
+                # heat-map heads: every map gets the same positive offset (~1.5 sigma) instead of a random
+                # one, like the positive peaks of a trained head; soft-max is shift invariant, and it keeps
+                # the reference's un-guarded division by sum_c(vc) (blocks.py:273-274) away from its pole
+                w = w - w.mean(axis=(0, 1, 2), keepdims=True) + head_offset
+            p.set(w.astype(np.float32))
+            p._synth_seed = seed
+        return gain * m2_in
+
+    for n in model._nodes:
+        ins = [est.get(t.uid, (0.0, 1.0)) for t in n.inputs]
+        mu, var = ins[0] if ins else (0.0, 1.0)
+        op = n.op
+        if op == 'conv':
+            p = n.layers['conv'].params[0]
+            gain = 2.0
+            head, d = feeds_decoder(n.outputs[0])
+            has_bn = any(c.op == 'bn' for c in consumers.get(n.outputs[0].uid, []))
+            is_head = head and not has_bn
+            if is_head:
+                gain = logit_std ** 2 * d / max(var, 1e-6)
+            off = 1.5 * logit_std * np.sqrt(d) / (p.fan_in * max(mu, 1e-3)) if is_head else None
+            out = (0.0, set_conv(p, p.fan_in, gain, var if is_head else var + mu * mu, head_offset=off))
+        elif op == 'sepconv':
+            layer = n.layers['sepconv']
+            v1 = set_conv(layer.params[0], layer.params[0].fan_in, 2.0, var + mu * mu)
+            out = (0.0, set_conv(layer.params[1], layer.params[1].fan_in, 1.0, v1))
+        elif op == 'bn':
+            layer = n.layers['bn']
+            for p in layer.params:
+                r = _rng(p.key, seed)
+                if p.role == 'mean':
+                    v = mu + r.standard_normal(p.shape) * 0.1 * np.sqrt(var)
+                elif p.role == 'var':
+                    v = var * r.uniform(0.6, 1.6, p.shape)
+                elif p.role == 'beta':
+                    v = r.standard_normal(p.shape) * 0.1
+                elif p.role == 'gamma':
+                    v = r.uniform(0.8, 1.2, p.shape)
+                p.set(np.asarray(v, np.float32))
+            out = (0.0, 1.0)
+        elif op == 'relu':
+            out = _relu_moments(mu, var)
+        elif op == 'add':
+            out = (sum(m for m, _ in ins), sum(v for _, v in ins))
+        elif op == 'concat':
+            cs = [t.shape[-1] for t in n.inputs]
+            tot = float(sum(cs))
+            m = sum(c * mi for c, (mi, _) in zip(cs, ins)) / tot
+            m2 = sum(c * (vi + mi * mi) for c, (mi, vi) in zip(cs, ins)) / tot
+            out = (m, max(m2 - m * m, 1e-12))
+        elif op == 'pool' and n.attrs.get('mode', 0) == 0:
+            e, v = _MAXPOOL.get(n.attrs['kh'] * n.attrs['kw'], (1.0, 0.5))
+            out = (mu + e * np.sqrt(var), var * v)
+        else:
+            out = (mu, var)
+        for o in n.outputs:
+            est[o.uid] = out
+    missing = [p.key for p in model.params if p.value is None]
+    if missing:
+        raise RuntimeError('init_synthetic left %d weights unset (first: %s)' % (len(missing), missing[0]))
+    return model
+
+
+def as_dict(model):
+    return {p.key: p.value for p in model.params}
+
+
+def save_weights(model, path):
+    d = as_dict(model)
+    missing = [k for k, v in d.items() if v is None]
+    if missing:
+        raise RuntimeError('cannot save: %d weights unset (first: %s)' % (len(missing), missing[0]))
+    np.savez(path, **d)
+
+
+def load_weights(model, path, by_name=False):
+    data = np.load(path)
+    keys = list(data.keys())
+    params = model.params
+    if keys and all(k.startswith('h5:') for k in keys):
+        _load_keras_order(params, data, keys, by_name)
+        return
+    have = set(keys)
+    missing = [p.key for p in params if p.key not in have]
+    if missing and not by_name:
+        raise ValueError('weight file %s lacks %d tensors of model %s (first: %s)' %
+                         (path, len(missing), model.name, missing[0]))
+    for p in params:
+        if p.key in have:
+            p.set(data[p.key])
+
+
+def _load_keras_order(params, data, keys, by_name):
+    """Keys 'h5:<idx>:<keras weight name>' as dumped by tools/h5_to_npz.py from layer_names/weight_names
+    order.  Frozen helper layers of the reference (soft-argmax convs, aggregation Dense: layers.py:180-194,
+    blocks.py:221-233) carry weights in the file but not in this engine; they are skipped by name."""
+    def is_frozen(name):
+        base = name.split('/')[-2] if '/' in name else name
+        return base.startswith('custom_sam_') or '_xy_' in base or base.startswith('dense_') or \
+            base.startswith('conv1d_')
+
+    ordered = sorted(keys, key=lambda k: int(k.split(':')[1]))
+    arrays = [(k.split(':', 2)[2], data[k]) for k in ordered if not is_frozen(k.split(':', 2)[2])]
+    if by_name:
+        byname = {n: a for n, a in arrays}
+        for p in params:
+            kn = '%s/%s:0' % (p.key.split('/')[-2], p.name)
+            if kn in byname:
+                p.set(byname[kn])
+        return
+    if len(arrays) != len(params):
+        raise ValueError('Keras file holds %d trainable tensors, model expects %d' % (len(arrays), len(params)))
+    for p, (n, a) in zip(params, arrays):
+        p.set(a)

@@ -1,0 +1,197 @@
+/*
+ * deephar_hip.h -- C-ABI of libdeephar_hip.so, the MI355X (gfx950) execution back-end for the
+ * pose-regression hot path of dluvizon/deephar.
+ *
+ * The reference has no FFI of its own: its arithmetic is reached through Keras 2.1.4 layer objects that
+ * lower to TensorFlow 1.6 kernels (reference deephar/layers.py:6-42, requirements.txt:2-3).  The seam is
+ * therefore "what a Keras layer call computes".  Each entry point below names the Keras layer(s) /
+ * reference function it replaces; the Python host (deephar_amd/) and any other host bind exactly these.
+ *
+ * Conventions
+ *   - fp32, NHWC ("channels_last", reference deephar/config.py:4).  A tensor view is (pointer, ld) where
+ *     ld = number of floats between consecutive pixels, so channel slices / concatenation targets are
+ *     expressed by pointer offset + ld (no copies for keras.layers.concatenate / Lambda slicing).
+ *   - all pointers are DEVICE pointers unless the name ends in _host; `stream` is a hipStream_t passed as
+ *     void*; every call is asynchronous on that stream and captures cleanly into a hipGraph.
+ *   - return value: 0 = OK, <0 = error (see dh_error_string).  Nothing throws, nothing allocates.
+ */
+#ifndef DEEPHAR_HIP_H_
+#define DEEPHAR_HIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DH_OK 0
+#define DH_EINVAL (-1)       /* bad argument / shape */
+#define DH_EUNSUPPORTED (-2) /* valid request the kernels do not cover */
+#define DH_ELAUNCH (-3)      /* HIP reported a launch/runtime error */
+
+int dh_version(void);
+const char* dh_error_string(int rc);
+/* name of the gfx target of device `dev`, CU count; rc<0 when no HIP device is visible */
+int dh_device_info(int dev, char* arch_name, int arch_name_len, int* cu_count);
+
+/* ---------------------------------------------------------------------------------------------------
+ * Conv2D (+ folded BatchNormalization / ReLU / add / UpSampling2D):
+ *   replaces layers.conv2d (layers.py:66-71) and its compositions conv_bn (:202), conv_act (:219),
+ *   conv_bn_act (:230), act_conv_bn (:258), act_conv (:317); the pointwise half of sepconv2d (:74-80,
+ *   288-301); common.residual_unit's BN->ReLU->conv chains (models/common.py:25-67).
+ *   y[m,co] = relu?( (sum_k pro(x)[m,k] * w[k,co]) * post_scale[co] + post_shift[co] + res1 + res2 )
+ *   pro(v)  = relu?( v * pre_scale[ci] + pre_shift[ci] ), applied to in-bounds taps only
+ *   Padding is explicit (pt, pl) so TF-"SAME" asymmetric padding is the caller's arithmetic.
+ *   up2 = 1 fuses keras UpSampling2D((2,2)) + add (reception.py:122-127): y is [N,2*OH,2*OW,Cout],
+ *   res1 is read at conv resolution, res2 at the up-sampled resolution.
+ * ------------------------------------------------------------------------------------------------- */
+typedef struct dh_conv_args {
+  const float* x;
+  const float* w; /* packed by dh_conv2d_pack_weights_host */
+  float* y;
+  const float* pre_scale;
+  const float* pre_shift;
+  const float* post_scale;
+  const float* post_shift;
+  const float* res1;
+  const float* res2;
+  int32_t N, H, W, Cin, ldx;
+  int32_t OH, OW, Cout, ldy;
+  int32_t KH, KW, SH, SW, PT, PL;
+  int32_t K;      /* KH*KW*Cin */
+  int32_t Kp, Np; /* padded dims of the packed weight */
+  int32_t ldr1, ldr2;
+  int32_t pre_relu, post_relu;
+  int32_t up2;
+} dh_conv_args;
+
+/* padded dims of the packed weight for a [KH,KW,Cin,Cout] (Keras HWIO) kernel */
+int dh_conv2d_packed_dims(int KH, int KW, int Cin, int Cout, int* Kp, int* Np);
+/* host-side repack HWIO -> [Kp/4][Np][4]; `packed_host` holds Kp*Np floats */
+int dh_conv2d_pack_weights_host(const float* w_hwio_host, float* packed_host, int KH, int KW, int Cin,
+                                int Cout);
+/* tile_cfg < 0: library heuristic; 0..dh_conv2d_num_tile_cfgs()-1 forces a tiling (autotuning hook) */
+int dh_conv2d_num_tile_cfgs(void);
+int dh_conv2d_pick_tile_cfg(int M, int Cout);
+int dh_conv2d_f32(const dh_conv_args* a, int tile_cfg, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------
+ * Depthwise KxK conv, stride 1, explicit padding: the depthwise half of keras SeparableConv2D
+ * (layers.py:74-80, 288-301; depth_multiplier 1, no bias).  w is [KH,KW,C] (= Keras [KH,KW,C,1]).
+ * ------------------------------------------------------------------------------------------------- */
+typedef struct dh_dw_args {
+  const float* x;
+  const float* w;
+  float* y;
+  const float* pre_scale;
+  const float* pre_shift;
+  int32_t N, H, W, C, ldx, ldy;
+  int32_t KH, KW, PT, PL;
+  int32_t pre_relu;
+} dh_dw_args;
+int dh_dwconv2d_f32(const dh_dw_args* a, void* stream);
+
+/* MaxPooling2D (reception.py:74,86,108,115; layers.py:92-97), padding cells ignored;
+ * mode 1 = layers.max_min_pooling (layers.py:411-425): maxpool(x) - maxpool(-x) */
+typedef struct dh_pool_args {
+  const float* x;
+  float* y;
+  int32_t N, H, W, C, ldx;
+  int32_t OH, OW, ldy;
+  int32_t KH, KW, SH, SW, PT, PL;
+  int32_t mode;
+} dh_pool_args;
+int dh_pool2d_f32(const dh_pool_args* a, void* stream);
+
+/* UpSampling2D((2,2)) [+ add]: y[n,h,w,c] = a[n,h,w,c] + b[n,h/2,w/2,c]; a may be NULL */
+int dh_upsample2x_add_f32(const float* a, int lda, const float* b, int ldb, float* y, int ldy, int N, int H,
+                          int W, int C, void* stream);
+
+/* element-wise glue: keras add / multiply / Activation('sigmoid') / standalone BatchNormalization+ReLU.
+ *   op 0: y = relu?( (a*scale+shift) + b + c )    op 1: y = (a*scale+shift) * b
+ *   op 2: y = sigmoid( (a*scale+shift) + b )      bcast_b: b has one channel, broadcast over C */
+typedef struct dh_elt_args {
+  const float* a;
+  const float* b;
+  const float* c;
+  float* y;
+  const float* scale;
+  const float* shift;
+  int32_t lda, ldb, ldc, ldy;
+  int64_t npix;
+  int32_t C;
+  int32_t relu;
+  int32_t op;
+  int32_t bcast_b;
+} dh_elt_args;
+int dh_eltwise_f32(const dh_elt_args* a, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------
+ * Soft-argmax decoder: activations.channel_softmax_2d (activations.py:3-16) + layers.lin_interpolation_2d /
+ * softargmax2d (layers.py:122-129,160-200) + keypoint_confidence / build_joints_probability
+ * (layers.py:107-119, blocks.py:328-343) in one pass over the maps.
+ *   xy[f,c]        = sum_hw softmax(alpha*h)[h,w,c] * (gx[w], gy[h])
+ *   conf_raw[f,c]  = max over 2x2 windows of conf_scale * (sum of the 4 raw values)
+ *   conf_prob[f,c] = the same on the soft-max probabilities (spnet.py:183)
+ *   prob           = the probability maps themselves (needed by kronecker_prod), may be NULL
+ *   gmax[f,c]      = max_hw h  (GlobalMaxPooling2D on the raw maps, reception.py:216), may be NULL
+ * ------------------------------------------------------------------------------------------------- */
+typedef struct dh_sam_args {
+  const float* h;
+  const float* gx;
+  const float* gy;
+  float* xy;
+  float* conf_raw;
+  float* conf_prob;
+  float* prob;
+  float* gmax;
+  int32_t F, H, W, C, ldh, ldxy, ldcr, ldcp, ldp;
+  float alpha;
+  float conf_scale;
+} dh_sam_args;
+int dh_softargmax2d_f32(const dh_sam_args* a, void* stream);
+
+/* blocks.build_context_aggregation (blocks.py:217-285); ys [F,J,2], yc [F,J*nctx,2], pc [F,J*nctx] */
+int dh_context_aggregation_f32(const float* ys, const float* yc, const float* pc, float* y, int F, int J,
+                               int nctx, float alpha, int ldy, void* stream);
+
+/* reception.pose_regression_3d (reception.py:193-222): depth/spatial means of the D*J maps ... */
+int dh_depth_means_f32(const float* h, int ldh, float* hxy, float* hz, int F, int HW, int D, int J,
+                       void* stream);
+/* ... and blocks.build_softargmax_1d (blocks.py:288-303, layers.py:132-157, activations.py:18-30);
+ * vz = max_d hz (GlobalMaxPooling1D, reception.py:217) */
+int dh_softargmax1d_f32(const float* hz, const float* grid, float* z, int ldz, float* vz, int F, int D, int J,
+                        void* stream);
+
+/* layers.kronecker_prod (layers.py:478-508): f[b,j,c] = sum_p hm[b,p,j] * x[b,p,c] */
+int dh_kronecker_f32(const float* hm, int ldh, const float* x, int ldx, float* f, int ldf, int B, int P, int J,
+                     int C, void* stream);
+
+/* layers.global_max_min_pooling (+ Activation('softmax')) (layers.py:428-442, action.py:14-17) */
+int dh_global_maxmin_softmax_f32(const float* x, int ldx, float* y, int B, int P, int C, int softmax,
+                                 void* stream);
+
+/* keras concatenate / Lambda channel slicing fallback, ZeroPadding2D (spnet.py:98-107) */
+int dh_copy_channels_f32(const float* x, int ldx, float* y, int ldy, int64_t npix, int C, void* stream);
+int dh_zeropad2d_f32(const float* x, float* y, int B, int H, int W, int C, int OH, int OW, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------
+ * Stream-ordered runtime helpers (no torch types): graphs for launch-bound replay, events for timing.
+ * ------------------------------------------------------------------------------------------------- */
+int dh_graph_begin_capture(void* stream);
+int dh_graph_end_capture(void* stream, void** graph_exec_out);
+int dh_graph_launch(void* graph_exec, void* stream);
+int dh_graph_destroy(void* graph_exec);
+
+int dh_event_create(void** event_out);
+int dh_event_record(void* event, void* stream);
+int dh_event_synchronize(void* event);
+int dh_event_elapsed_ms(void* start, void* stop, float* ms_out);
+int dh_event_destroy(void* event);
+int dh_stream_synchronize(void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DEEPHAR_HIP_H_ */

@@ -1,0 +1,30 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu on the GPU box)')
+
+
+@pytest.fixture(scope='session')
+def hip_lib():
+    """Make sure the in-tree HIP library exists (hipcc cross-compiles without a GPU)."""
+    from deephar_amd import _lib
+    if not os.path.exists(_lib.LIB_PATH):
+        from deephar_amd.csrc import build
+        build.build(verbose=False)
+    return _lib.load()
+
+
+@pytest.fixture(scope='session')
+def cuda():
+    import torch
+    if not torch.cuda.is_available():
+        pytest.fail('-m gpu tests need a HIP device; none visible')
+    return torch.device('cuda:0')

@@ -1,0 +1,253 @@
+"""Op-level parity: every kernel entry point of the C-ABI vs the CPU oracle on seeded inputs.
+
+fp32 tolerance: the kernels and the oracle both compute in IEEE fp32 but sum in different orders
+(MFMA k-ordered fmaf chain vs oneDNN blocking), so outputs are compared with
+|hip - oracle| <= ATOL + RTOL * |oracle|, RTOL = 2e-5 (a few ulp times sqrt(K)), scaled ATOL.
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import ops as O
+
+pytestmark = pytest.mark.gpu
+
+RTOL = 2e-5
+
+
+def _rand(rng, shape, scale=1.0):
+    return (rng.standard_normal(shape) * scale).astype(np.float32)
+
+
+def _close(got, ref, atol, rtol=RTOL, what=''):
+    got = got.detach().cpu().numpy() if torch.is_tensor(got) else got
+    ref = ref.detach().cpu().numpy() if torch.is_tensor(ref) else ref
+    assert got.shape == ref.shape, (what, got.shape, ref.shape)
+    err = np.abs(got - ref)
+    tol = atol + rtol * np.abs(ref)
+    assert np.all(err <= tol), '%s: max err %.3e (tol %.3e) at %s' % (
+        what, err.max(), tol.flat[err.argmax()], np.unravel_index(err.argmax(), err.shape))
+
+
+CONV_CASES = [
+    # (N, H, W, Cin, Cout, kh, kw, stride, padding)
+    (2, 32, 32, 576, 576, 1, 1, 1, 'same'),     # the dominant pointwise GEMM
+    (3, 16, 16, 288, 288, 1, 1, 1, 'same'),
+    (2, 32, 32, 576, 48, 1, 1, 1, 'same'),      # RegMap: Cout not a multiple of 32
+    (2, 32, 32, 48, 576, 1, 1, 1, 'same'),      # fReMap: K not a multiple of 32
+    (2, 64, 64, 3, 32, 3, 3, 2, 'same'),        # first stem conv: Cin=3 (scalar gather), TF-SAME stride 2
+    (2, 33, 31, 32, 64, 3, 3, 1, 'same'),       # odd sizes, ragged M
+    (1, 32, 32, 64, 96, 3, 3, 2, 'same'),
+    (2, 20, 24, 64, 64, 5, 1, 1, 'same'),
+    (2, 20, 24, 64, 64, 1, 5, 1, 'same'),
+    (1, 40, 40, 8, 64, 7, 7, 2, 'same'),        # SPNet entry-flow shape class (7x7 s2)
+    (2, 16, 16, 2, 24, 3, 5, 1, 'same'),        # action-head conv over the (T,J) plane, Cin=2
+    (1, 9, 9, 160, 64, 1, 1, 1, 'valid'),
+    (1, 12, 12, 32, 32, 3, 3, 1, 'valid'),
+]
+
+
+@pytest.mark.parametrize('case', CONV_CASES)
+def test_conv2d_plain(case, hip_lib, cuda):
+    from deephar_amd import functional as F
+    n, h, w, cin, cout, kh, kw, s, pad = case
+    rng = np.random.default_rng(sum(v for v in case if isinstance(v, int)))
+    x = _rand(rng, (n, h, w, cin))
+    k = _rand(rng, (kh, kw, cin, cout), np.sqrt(1.0 / (kh * kw * cin)))
+    ref = O.conv2d(torch.from_numpy(x), torch.from_numpy(k), (s, s), pad)
+    ref64 = O.conv2d(torch.from_numpy(x).double(), torch.from_numpy(k).double(), (s, s), pad)
+    got = F.conv2d(torch.from_numpy(x).to(cuda), k, (s, s), pad)
+    torch.cuda.synchronize()
+    _close(got, ref, atol=2e-5, what='conv %s' % (case,))
+    # and not further from the fp64 truth than a few times the fp32 CPU result is
+    e_hip = (got.cpu().double() - ref64).abs().max().item()
+    e_cpu = (ref.double() - ref64).abs().max().item()
+    assert e_hip <= 4 * e_cpu + 1e-6, (e_hip, e_cpu)
+
+
+@pytest.mark.parametrize('cfg', range(9))
+def test_conv2d_every_tile_config(cfg, hip_lib, cuda):
+    from deephar_amd import functional as F
+    assert hip_lib.dh_conv2d_num_tile_cfgs() == 9
+    rng = np.random.default_rng(cfg)
+    x = _rand(rng, (2, 19, 23, 96))          # M = 874: ragged in every BM
+    k = _rand(rng, (3, 3, 96, 200), 0.05)    # Cout = 200: ragged in every BN
+    ref = O.conv2d(torch.from_numpy(x), torch.from_numpy(k))
+    got = F.conv2d(torch.from_numpy(x).to(cuda), k, tile_cfg=cfg)
+    torch.cuda.synchronize()
+    _close(got, ref, atol=3e-5, what='cfg %d' % cfg)
+
+
+def test_conv2d_fused_prologue_epilogue(hip_lib, cuda):
+    """BN -> ReLU -> conv -> BN -> (+res1 +res2) -> ReLU in one launch vs the unfused oracle chain."""
+    from deephar_amd import functional as F
+    rng = np.random.default_rng(7)
+    n, h, w, cin, cout = 2, 16, 16, 64, 96
+    x = _rand(rng, (n, h, w, cin))
+    k = _rand(rng, (3, 3, cin, cout), 0.06)
+    ps, pb = rng.uniform(0.5, 1.5, cin).astype(np.float32), _rand(rng, (cin,), 0.3)
+    qs, qb = rng.uniform(0.5, 1.5, cout).astype(np.float32), _rand(rng, (cout,), 0.3)
+    r1, r2 = _rand(rng, (n, h, w, cout)), _rand(rng, (n, h, w, cout))
+    t = lambda a: torch.from_numpy(a)
+    ref = O.relu(t(x) * t(ps) + t(pb))               # zero padding happens AFTER the activation
+    ref = O.conv2d(ref, t(k)) * t(qs) + t(qb) + t(r1) + t(r2)
+    ref_relu = O.relu(ref)
+    d = lambda a: torch.from_numpy(a).to(cuda)
+    got = F.conv2d(d(x), k, pre_scale=d(ps), pre_shift=d(pb), pre_relu=True, post_scale=d(qs), post_shift=d(qb),
+                   res1=d(r1), res2=d(r2))
+    got_relu = F.conv2d(d(x), k, pre_scale=d(ps), pre_shift=d(pb), pre_relu=True, post_scale=d(qs),
+                        post_shift=d(qb), res1=d(r1), res2=d(r2), post_relu=True)
+    torch.cuda.synchronize()
+    _close(got, ref, atol=3e-5, what='fused')
+    _close(got_relu, ref_relu, atol=3e-5, what='fused+relu')
+
+
+def test_conv2d_prologue_keeps_padding_zero(hip_lib, cuda):
+    """A pre-affine with a positive shift must not leak into the zero padding (TF pads after BN+ReLU)."""
+    from deephar_amd import functional as F
+    x = np.zeros((1, 6, 6, 4), np.float32)
+    k = np.ones((3, 3, 4, 32), np.float32)
+    ps, pb = np.ones(4, np.float32), np.full(4, 2.0, np.float32)
+    d = lambda a: torch.from_numpy(a).to(cuda)
+    got = F.conv2d(d(x), k, pre_scale=d(ps), pre_shift=d(pb), pre_relu=True).cpu().numpy()
+    # interior: 9 taps * 4 ch * 2.0 = 72 ; corner: 4 taps * 4 * 2 = 32
+    assert got[0, 3, 3, 0] == 72.0 and got[0, 0, 0, 0] == 32.0 and got[0, 0, 3, 5] == 48.0
+
+
+@pytest.mark.parametrize('cout,cfg', [(288, -1), (576, -1), (96, 5), (64, 1)])
+def test_conv2d_fused_upsample_add(cout, cfg, hip_lib, cuda):
+    """conv -> BN -> +res1 -> UpSampling2D -> +res2 (reception.py:122-127) in the conv epilogue."""
+    from deephar_amd import functional as F
+    rng = np.random.default_rng(cout)
+    n, h, w, cin = 2, 8, 8, 288
+    x, k = _rand(rng, (n, h, w, cin)), _rand(rng, (1, 1, cin, cout), 0.06)
+    qs, qb = rng.uniform(0.5, 1.5, cout).astype(np.float32), _rand(rng, (cout,), 0.3)
+    r1, r2 = _rand(rng, (n, h, w, cout)), _rand(rng, (n, 2 * h, 2 * w, cout))
+    t = lambda a: torch.from_numpy(a)
+    ref = O.upsample2d(O.conv2d(t(x), t(k)) * t(qs) + t(qb) + t(r1)) + t(r2)
+    d = lambda a: torch.from_numpy(a).to(cuda)
+    got = F.conv2d(d(x), k, post_scale=d(qs), post_shift=d(qb), res1=d(r1), res2=d(r2), up2=True, tile_cfg=cfg)
+    torch.cuda.synchronize()
+    _close(got, ref, atol=3e-5, what='up2')
+
+
+@pytest.mark.parametrize('shape,k', [((2, 32, 32, 576), 5), ((3, 16, 16, 288), 5), ((2, 8, 8, 288), 5),
+                                     ((2, 32, 32, 384), 3), ((1, 7, 9, 20), 5), ((2, 5, 6, 6), 3),
+                                     ((2, 16, 16, 16), 1)])
+def test_dwconv(shape, k, hip_lib, cuda):
+    from deephar_amd import functional as F
+    rng = np.random.default_rng(shape[3] + k)
+    x = _rand(rng, shape)
+    dw = _rand(rng, (k, k, shape[3], 1), 1.0 / k)
+    ps, pb = rng.uniform(0.5, 1.5, shape[3]).astype(np.float32), _rand(rng, (shape[3],), 0.3)
+    t = lambda a: torch.from_numpy(a)
+    d = lambda a: torch.from_numpy(a).to(cuda)
+    _close(F.dwconv2d(d(x), dw), O.depthwise_conv2d(t(x), t(dw)), atol=1e-5, what='dw plain')
+    _close(F.dwconv2d(d(x), dw, pre_relu=True), O.depthwise_conv2d(O.relu(t(x)), t(dw)), atol=1e-5, what='dw relu')
+    _close(F.dwconv2d(d(x), dw, pre_scale=d(ps), pre_shift=d(pb), pre_relu=True),
+           O.depthwise_conv2d(O.relu(t(x) * t(ps) + t(pb)), t(dw)), atol=1e-5, what='dw bn relu')
+
+
+@pytest.mark.parametrize('shape,pool,strides,pad', [
+    ((2, 128, 128, 64), (3, 3), (2, 2), 'same'), ((2, 64, 64, 192), (2, 2), (2, 2), 'valid'),
+    ((2, 32, 32, 576), (2, 2), None, 'valid'), ((2, 16, 17, 30), (2, 2), (2, 2), 'same'),
+    ((1, 9, 7, 5), (3, 3), (2, 2), 'same'), ((2, 32, 20, 8), (2, 2), (2, 2), 'same')])
+def test_pool_bit_exact(shape, pool, strides, pad, hip_lib, cuda):
+    from deephar_amd import functional as F
+    rng = np.random.default_rng(sum(shape))
+    x = _rand(rng, shape)
+    ref = O.maxpool2d(torch.from_numpy(x), pool, strides, pad)
+    got = F.pool2d(torch.from_numpy(x).to(cuda), pool, strides, pad).cpu()
+    assert torch.equal(got, ref)
+    if pool == (2, 2) and pad == 'same':
+        ref = O.max_min_pooling(torch.from_numpy(x), pool, pad)
+        got = F.pool2d(torch.from_numpy(x).to(cuda), pool, strides, pad, mode=1).cpu()
+        assert torch.equal(got, ref)
+
+
+def test_upsample_add_bit_exact(hip_lib, cuda):
+    from deephar_amd import functional as F
+    rng = np.random.default_rng(5)
+    a, b = _rand(rng, (2, 16, 16, 288)), _rand(rng, (2, 8, 8, 288))
+    ref = torch.from_numpy(a) + O.upsample2d(torch.from_numpy(b))
+    got = F.upsample2x_add(torch.from_numpy(b).to(cuda), torch.from_numpy(a).to(cuda)).cpu()
+    assert torch.equal(got, ref)
+    assert torch.equal(F.upsample2x_add(torch.from_numpy(b).to(cuda)).cpu(), O.upsample2d(torch.from_numpy(b)))
+
+
+@pytest.mark.parametrize('shape,alpha', [((4, 32, 32, 16), 1.0), ((3, 32, 32, 32), 1.0), ((2, 32, 32, 17), 1.0),
+                                         ((2, 16, 16, 17), 2.5), ((3, 8, 8, 20), 1.0), ((2, 4, 4, 17), 0.7),
+                                         ((1, 32, 32, 272), 1.0)])
+def test_softargmax2d(shape, alpha, hip_lib, cuda):
+    """Coordinates within 1e-3 px of a 256-px crop (|d| <= 3.9e-6 in normalised units)."""
+    from deephar_amd import functional as F
+    rng = np.random.default_rng(shape[3])
+    h = _rand(rng, shape, 4.0)
+    t = torch.from_numpy(h)
+    out = F.softargmax2d(t.to(cuda), alpha=alpha, conf_scale=4.0, want_prob=True)
+    p = O.channel_softmax_2d(t, alpha)
+    p64 = O.channel_softmax_2d(t.double(), alpha)
+    xy64 = O.softargmax2d_from_prob(p64)
+    xy = out['xy'].cpu()
+    assert (xy.double() - xy64).abs().max().item() <= 3.9e-6 / 2
+    assert (xy - O.softargmax2d_from_prob(p)).abs().max().item() <= 3.9e-6
+    _close(out['prob'], p, atol=1e-9, rtol=1e-5, what='prob')
+    _close(out['conf_raw'], O.joints_probability(4.0 * t), atol=1e-5, what='conf_raw')
+    _close(out['conf_prob'], O.joints_probability(p), atol=1e-9, rtol=1e-5, what='conf_prob')
+    assert torch.equal(out['gmax'].cpu(), torch.amax(t, dim=(1, 2)))
+
+
+def test_softargmax2d_known_answers(hip_lib, cuda):
+    from deephar_amd import functional as F
+    H = W = 32
+    h = np.full((1, H, W, 3), -1e4, np.float32)
+    pts = [(0, 0), (H - 1, W - 1), (7, 20)]
+    for c, (r, q) in enumerate(pts):
+        h[0, r, q, c] = 30.0
+    xy = F.softargmax2d(torch.from_numpy(h).to(cuda))['xy'].cpu().numpy()[0]
+    for c, (r, q) in enumerate(pts):
+        np.testing.assert_allclose(xy[c], [np.float32(q / (W - 1)), np.float32(r / (H - 1))], atol=1e-7)
+    flat = F.softargmax2d(torch.zeros(2, 16, 16, 5, device=cuda))['xy'].cpu().numpy()
+    np.testing.assert_allclose(flat, 0.5, atol=1e-6)
+
+
+def test_context_aggregation(hip_lib, cuda):
+    from deephar_amd import functional as F
+    rng = np.random.default_rng(11)
+    ys, yc = rng.random((5, 16, 2)).astype(np.float32), rng.random((5, 32, 2)).astype(np.float32)
+    pc = rng.uniform(0.5, 3.0, (5, 32, 1)).astype(np.float32)
+    ref = O.context_aggregation(torch.from_numpy(ys), torch.from_numpy(yc), torch.from_numpy(pc), 16, 2, 0.8)
+    d = lambda a: torch.from_numpy(a).to(cuda)
+    _close(F.context_aggregation(d(ys), d(yc), d(pc), 2, 0.8), ref, atol=2e-7, rtol=1e-6, what='agg')
+
+
+def test_pose3d_pieces(hip_lib, cuda):
+    from deephar_amd import functional as F
+    rng = np.random.default_rng(12)
+    D, J = 16, 17
+    h = _rand(rng, (3, 32, 32, D * J), 3.0)
+    t = torch.from_numpy(h)
+    h5 = t.reshape(3, 32, 32, D, J)
+    hxy, hz = F.depth_means(t.to(cuda), D, J)
+    _close(hxy, h5.mean(dim=3), atol=2e-6, what='hxy')
+    _close(hz, h5.mean(dim=(1, 2)), atol=2e-6, what='hz')
+    z, vz = F.softargmax1d(hz)
+    ref_z = O.softargmax1d(h5.double().mean(dim=(1, 2)))
+    assert (z.cpu().double() - ref_z).abs().max().item() <= 3.9e-6
+    _close(vz, torch.amax(h5.mean(dim=(1, 2)), dim=1), atol=2e-6, what='vz')
+
+
+def test_kronecker_and_action_top(hip_lib, cuda):
+    from deephar_amd import functional as F
+    rng = np.random.default_rng(13)
+    hm = rng.random((6, 32, 32, 16)).astype(np.float32)
+    hm /= hm.sum(axis=(1, 2), keepdims=True)
+    x = _rand(rng, (6, 32, 32, 576))
+    ref = O.kronecker_prod(torch.from_numpy(hm).double(), torch.from_numpy(x).double())
+    got = F.kronecker(torch.from_numpy(hm).to(cuda), torch.from_numpy(x).to(cuda))
+    _close(got.cpu().double(), ref, atol=2e-6, rtol=1e-5, what='kron')
+    a = _rand(rng, (4, 8, 10, 60), 2.0)
+    ref = torch.softmax(O.global_max_min_pooling(torch.from_numpy(a)), dim=-1)
+    _close(F.global_maxmin_softmax(torch.from_numpy(a).to(cuda)), ref, atol=1e-8, rtol=1e-5, what='action_top')
+    ref = O.global_max_min_pooling(torch.from_numpy(a))
+    assert torch.equal(F.global_maxmin_softmax(torch.from_numpy(a).to(cuda), softmax=False).cpu(), ref)

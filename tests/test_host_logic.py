@@ -1,0 +1,224 @@
+"""CPU tests of the host logic: C-ABI surface, weight packing, graph builders, planner/fusion, memory plan,
+weights, naming agreement between the product builders and the independent oracle.  No GPU compute."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+
+def test_capi_exports_every_declared_symbol(hip_lib):
+    from deephar_amd import _lib
+    hdr = open(os.path.join(os.path.dirname(_lib._HERE), 'include', 'deephar_hip.h')).read()
+    declared = set(re.findall(r'\b(dh_[a-z0-9_]+)\s*\(', hdr))
+    assert declared, 'no prototypes parsed'
+    assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
+    for name in declared:
+        assert hasattr(hip_lib, name), name
+    assert hip_lib.dh_version() >= 100
+    assert hip_lib.dh_error_string(-2).decode().startswith('configuration')
+
+
+def test_ctypes_structs_match_header_layout(hip_lib):
+    """Field order/size of the ctypes mirrors vs the C structs (9 pointers + 23 ints etc.)."""
+    from deephar_amd import _lib
+    assert ctypes.sizeof(_lib.ConvArgs) == 9 * 8 + 23 * 4 + 4      # padded to 8
+    assert ctypes.sizeof(_lib.DwArgs) == 5 * 8 + 11 * 4 + 4
+    assert ctypes.sizeof(_lib.PoolArgs) == 2 * 8 + 15 * 4 + 4
+    assert ctypes.sizeof(_lib.EltArgs) == 6 * 8 + 4 * 4 + 8 + 4 * 4
+    assert ctypes.sizeof(_lib.SamArgs) == 8 * 8 + 9 * 4 + 2 * 4 + 4
+
+
+def test_weight_packing_roundtrip_and_layout(hip_lib):
+    from deephar_amd.engine import packing
+    rng = np.random.default_rng(0)
+    for shape in [(1, 1, 576, 576), (3, 3, 3, 32), (1, 1, 48, 576), (5, 1, 64, 64), (1, 1, 576, 48), (3, 5, 2, 24)]:
+        w = rng.standard_normal(shape).astype(np.float32)
+        packed, kp, np_ = packing.pack_conv(w)
+        k = shape[0] * shape[1] * shape[2]
+        assert kp % 32 == 0 and np_ % 32 == 0 and kp >= k and np_ >= shape[3] and packed.size == kp * np_
+        assert np.array_equal(packing.unpack_conv(packed, *shape), w)
+        # [Kp/4][Np][4]: element (k, n) sits at ((k//4)*Np + n)*4 + k%4 ; padding is zero
+        flat = w.reshape(k, shape[3])
+        kk, nn = k - 1, shape[3] - 1
+        assert packed[((kk // 4) * np_ + nn) * 4 + kk % 4] == flat[kk, nn]
+        assert np.count_nonzero(packed) == np.count_nonzero(w)
+    assert hip_lib.dh_conv2d_pack_weights_host(None, None, 1, 1, 1, 1) == -1
+
+
+def test_tile_heuristic_prefers_full_tiles(hip_lib):
+    pick = hip_lib.dh_conv2d_pick_tile_cfg
+    assert pick(65536, 576) == 0          # 128x192 divides 576
+    assert pick(65536, 288) in (2, 5)     # 96-wide tiles
+    assert pick(65536, 48) in (3, 6)      # padded to 64
+    assert pick(64, 32) == 8
+    for m in (1, 100, 4096, 10 ** 6):
+        for c in (1, 17, 48, 160, 272, 576):
+            assert 0 <= pick(m, c) < hip_lib.dh_conv2d_num_tile_cfgs()
+
+
+def _mpii(blocks=2, **kw):
+    from deephar_amd import graph
+    from deephar_amd.models import reception
+    graph.reset_naming()
+    kw.setdefault('num_context_per_joint', 2)
+    return reception.build((256, 256, 3), 16, dim=2, num_blocks=blocks, ksize=(5, 5), **kw)
+
+
+def test_reception_graph_matches_survey_numbers():
+    m = _mpii(8, concat_pose_confidence=False)
+    assert m.count_params() == 14746560                      # 14.75 M
+    assert abs(m.plan.total_flops() / 2e9 - 9.833) < 0.005   # 9.833 GMAC / frame
+    assert len(m.outputs) == 16
+    assert [t.shape for t in m.outputs[:2]] == [(16, 2), (16, 1)]
+    assert m.input_shape == (None, 256, 256, 3) and m.get_input_shape_at(0) == (None, 256, 256, 3)
+    names = [l.name for l in m.layers]
+    for want in ['Stem', 'rBlock1', 'SepConv1', 'RegMap1', 'fReMap1', 'sSAM', 'cSAM', 'sjProb', 'cjProb', 'Agg',
+                 'rBlock8', 'RegMap8']:
+        assert want in names
+    assert 'fReMap8' not in names
+    assert m.get_layer('Stem').count_params() > 0
+
+
+def test_h36m_graph():
+    from deephar_amd import graph
+    from deephar_amd.models import reception
+    graph.reset_naming()
+    m = reception.build((256, 256, 3), 17, dim=3, num_blocks=8, depth_maps=16, ksize=(5, 5))
+    assert abs(m.count_params() / 1e6 - 16.68) < 0.01
+    assert abs(m.plan.total_flops() / 2e9 - 11.814) < 0.005
+    assert [t.shape for t in m.outputs] == [(17, 4)] * 8
+    with pytest.raises(ValueError):
+        reception.build((256, 256, 3), 16, dim=4)
+    with pytest.raises(AssertionError):
+        reception.build((256, 256, 3), 17, dim=3, num_context_per_joint=2)
+
+
+def test_planner_fusion_rules():
+    m = _mpii(2, concat_pose_confidence=True)
+    plan = m.plan
+    kinds = [s.kind for s in plan.steps]
+    # nothing but kernels that exist; BN / ReLU / add / concat / upsample never survive as their own launch
+    assert set(kinds) <= {'conv', 'dwconv', 'pool', 'sam', 'context_agg'}
+    convs = [s for s in plan.steps if s.kind == 'conv']
+    assert sum(1 for s in convs if s.attrs['up2']) == 4            # two fused up-samplings per hourglass
+    assert any('res1' in s.ins and 'res2' in s.ins and not s.attrs['up2'] for s in convs)   # 3-way add
+    first = plan.steps[0]
+    assert first.attrs['post_relu'] == 1 and 'post_bn' in first.params and first.attrs['pt'] == 0  # TF-SAME s2
+    # concat targets are written in place at channel offsets
+    y = [s for s in plan.steps if s.kind == 'pool'][0].outs['y']
+    assert (y.coff, y.ld) == (96, 160)
+    # decoder: heat-map slices are views; (x,y) and confidence land directly in the [J,3] output
+    sams = [s for s in plan.steps if s.kind == 'sam']
+    assert (sams[0].ins['h'].coff, sams[0].ins['h'].ld, sams[0].ins['h'].C) == (0, 48, 16)
+    assert (sams[1].ins['h'].coff, sams[1].ins['h'].C) == (16, 32)
+    assert sams[0].outs['conf_raw'].ld == 3 and sams[0].outs['conf_raw'].coff == 2
+
+
+def test_memory_plan_has_no_live_overlap():
+    plan = _mpii(3).plan
+    bufs = plan.bufs
+    assert plan.arena_items >= max(b.offset + b.items for b in bufs)
+    for i, a in enumerate(bufs):
+        assert a.offset % 4 == 0
+        for b in bufs[i + 1:]:
+            live = not (a.end < b.start or b.end < a.start)
+            space = not (a.offset + a.items <= b.offset or b.offset + b.items <= a.offset)
+            assert not (live and space), 'two live buffers share arena space'
+    # reuse actually happens: arena far smaller than the sum of all buffers
+    assert plan.arena_items < 0.35 * sum(b.items for b in bufs)
+    # every step's operands are alive at that step
+    for i, s in enumerate(plan.steps):
+        for v in list(s.ins.values()) + list(s.outs.values()):
+            assert v.buf.start <= i <= v.buf.end
+
+
+def test_weights_roundtrip_and_determinism(tmp_path):
+    from deephar_amd import weights
+    m = _mpii(1)
+    with pytest.raises(RuntimeError):
+        weights.save_weights(m, str(tmp_path / 'w.npz'))
+    weights.init_synthetic(m, seed=3)
+    a = weights.as_dict(m)
+    path = str(tmp_path / 'w.npz')
+    m.save_weights(path)
+    m2 = _mpii(1)
+    m2.load_weights(path)
+    for k, v in weights.as_dict(m2).items():
+        assert np.array_equal(v, a[k])
+    m3 = _mpii(1)
+    weights.init_synthetic(m3, seed=3)
+    assert all(np.array_equal(v, a[k]) for k, v in weights.as_dict(m3).items())
+    weights.init_synthetic(m3, seed=4)
+    assert not np.array_equal(weights.as_dict(m3)['Stem/conv2d_1/kernel'], a['Stem/conv2d_1/kernel'])
+    with pytest.raises(ValueError):
+        m3.get_layer('Stem').layers[0].set_weights([np.zeros((1, 1, 1, 1))])
+
+
+def test_oracle_and_builder_agree_on_names_and_shapes():
+    """Independent restatements: the oracle walks the reference's source order and must ask for exactly the
+    weights the product builder created (names + shapes), and use all of them."""
+    import torch
+    from deephar_amd import weights
+    from oracle import reception as oref
+    from oracle.naming import Weights
+    m = _mpii(2, concat_pose_confidence=False)
+    weights.init_synthetic(m)
+    ow = Weights(weights.as_dict(m))
+    x = np.random.default_rng(0).uniform(-1, 1, (1, 256, 256, 3)).astype(np.float32)
+    outs = oref.forward(ow, x, 16, 2, num_context_per_joint=2, num_blocks=2, ksize=(5, 5),
+                        concat_pose_confidence=False)
+    assert ow.unused() == []
+    assert [o.shape[1:] for o in outs] == [t.shape for t in m.outputs]
+    assert all(np.all(np.isfinite(o)) for o in outs)
+
+
+def test_synthetic_weights_keep_activations_sane():
+    """heat-map logits must be neither flat nor one-hot, context confidences away from 0."""
+    import torch
+    from deephar_amd import weights
+    from oracle import reception as oref
+    m = _mpii(4, concat_pose_confidence=False)
+    weights.init_synthetic(m)
+    x = np.random.default_rng(1).uniform(-1, 1, (2, 256, 256, 3)).astype(np.float32)
+    taps = {}
+    oref.forward(weights.as_dict(m), x, 16, 2, num_context_per_joint=2, num_blocks=4, ksize=(5, 5),
+                 concat_pose_confidence=False, taps=taps)
+    for b in (1, 4):
+        assert 1.0 < taps['heatmaps%d' % b].std() < 30.0
+        assert 0.3 < taps['rblock%d' % b].std() < 30.0
+        assert taps['vc%d' % b].reshape(2, 16, 2).sum(axis=2).min() > 1.0
+
+
+def test_model_api_errors():
+    from deephar_amd import Model, layers
+    m = _mpii(1)
+    with pytest.raises(ValueError):
+        m.get_layer('nope')
+    with pytest.raises(ValueError):
+        Model(layers.Input((4, 4, 3)), m.outputs[0])      # disconnected graph
+    with pytest.raises(TypeError):
+        Model(m.input, [1.0])
+    sub = m.get_layer('rBlock1')
+    y = sub(layers.Input((7, 32, 32, 576)))               # TimeDistributed-style call: leading T dim
+    assert y.shape == (7, 32, 32, 576)
+    with pytest.raises(ValueError):
+        sub(layers.Input((16, 16, 576)))
+
+
+def test_no_cpu_execution_path():
+    """Without a GPU predict() must fail loudly, never fall back to the oracle or torch-CPU."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip('GPU present')
+    from deephar_amd import weights
+    from deephar_amd._lib import DeepharHipError
+    m = _mpii(1)
+    weights.init_synthetic(m)
+    with pytest.raises(DeepharHipError):
+        m.predict(np.zeros((1, 256, 256, 3), np.float32))
+    import deephar_amd
+    src = ''.join(open(os.path.join(os.path.dirname(deephar_amd.__file__), f)).read()
+                  for f in ('model.py', 'engine/executor.py', 'engine/planner.py', 'functional.py', 'layers.py'))
+    assert 'import oracle' not in src and 'from oracle' not in src

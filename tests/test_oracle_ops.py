@@ -1,0 +1,173 @@
+"""Pin the CPU oracle with analytic known answers and a second, independent NumPy-fp64 statement of the
+decoder ops (the reference has no golden vectors: parity is otherwise unpinned, see oracle/__init__.py)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import ops
+
+
+def test_same_padding_is_tf_asymmetric():
+    # 3x3 s2 on even sizes pads (0 top/left, 1 bottom/right); 7x7 s2 -> (2,3); 5x5 s1 -> (2,2)
+    assert ops.same_pad(256, 3, 2) == (0, 1, 128)
+    assert ops.same_pad(256, 7, 2) == (2, 3, 128)
+    assert ops.same_pad(32, 5, 1) == (2, 2, 32)
+    assert ops.same_pad(64, 1, 1) == (0, 0, 64)
+    assert ops.same_pad(17, 2, 2) == (0, 1, 9)
+
+
+def test_conv_same_stride2_uses_bottom_right_padding():
+    x = torch.zeros(1, 4, 4, 1)
+    x[0, 3, 3, 0] = 1.0          # bottom-right pixel
+    k = torch.zeros(3, 3, 1, 1)
+    k[0, 0, 0, 0] = 1.0          # top-left tap
+    y = ops.conv2d(x, k, (2, 2), 'same')
+    # out(1,1) reads in(2..4, 2..4) (pad after): top-left tap hits in(2,2)=0 ; out(1,1) with tap (1,1) would hit (3,3)
+    assert y.shape == (1, 2, 2, 1) and float(y.abs().sum()) == 0.0
+    k = torch.zeros(3, 3, 1, 1)
+    k[1, 1, 0, 0] = 1.0
+    y = ops.conv2d(x, k, (2, 2), 'same')
+    assert float(y[0, 1, 1, 0]) == 1.0   # symmetric (torch-style) padding would put it elsewhere
+
+
+def test_identity_pointwise_and_depthwise():
+    rng = np.random.default_rng(0)
+    x = torch.from_numpy(rng.standard_normal((2, 6, 5, 4)).astype(np.float32))
+    eye = torch.eye(4).reshape(1, 1, 4, 4)
+    assert torch.equal(ops.conv2d(x, eye), x)
+    dw = torch.zeros(5, 5, 4, 1)
+    dw[2, 2, :, 0] = 1.0
+    assert torch.equal(ops.depthwise_conv2d(x, dw), x)
+    assert torch.equal(ops.sepconv2d(x, dw, eye), x)
+
+
+def test_batchnorm_formula():
+    x = torch.tensor([[[[1.0, 2.0]]]])
+    y = ops.batchnorm(x, beta=torch.tensor([0.5, -0.5]), mean=torch.tensor([1.0, 0.0]),
+                      var=torch.tensor([3.0, 0.999]))
+    exp = np.array([0.5, -0.5 + 2.0 / np.sqrt(0.999 + 1e-3)], dtype=np.float32)
+    np.testing.assert_allclose(y.numpy().ravel(), exp, rtol=1e-6)
+    y2 = ops.batchnorm(x, torch.zeros(2), torch.zeros(2), torch.ones(2) - 1e-3, gamma=torch.tensor([2.0, 3.0]))
+    np.testing.assert_allclose(y2.numpy().ravel(), [2.0, 6.0], rtol=1e-6)
+
+
+def test_maxpool_same_ignores_padding():
+    x = -torch.ones(1, 3, 3, 1)
+    y = ops.maxpool2d(x, (3, 3), (2, 2), 'same')
+    assert y.shape == (1, 2, 2, 1) and torch.all(y == -1)   # zero padding would give 0
+    y = ops.maxpool2d(x, (2, 2))
+    assert y.shape == (1, 1, 1, 1)
+
+
+def test_upsample_nearest():
+    x = torch.arange(4.0).reshape(1, 2, 2, 1)
+    y = ops.upsample2d(x)
+    assert y[0, :, :, 0].tolist() == [[0, 0, 1, 1], [0, 0, 1, 1], [2, 2, 3, 3], [2, 2, 3, 3]]
+
+
+@pytest.mark.parametrize('hw', [(32, 32), (8, 16)])
+def test_softargmax_of_peaked_map_is_grid_coordinate(hw):
+    H, W = hw
+    h = torch.full((1, H, W, 3), -1e4)
+    pts = [(0, 0), (H - 1, W - 1), (H // 2, 3)]
+    for c, (r, q) in enumerate(pts):
+        h[0, r, q, c] = 50.0
+    xy = ops.softargmax2d(h).numpy()[0]
+    for c, (r, q) in enumerate(pts):
+        # endpoints 0 and 1 inclusive (np.linspace(0,1,W)), not pixel centres
+        np.testing.assert_allclose(xy[c], [q / (W - 1), r / (H - 1)], atol=1e-6)
+
+
+def test_softargmax_of_constant_map_is_centre_and_probs_sum_to_one():
+    h = torch.zeros(2, 16, 16, 5)
+    p = ops.channel_softmax_2d(h)
+    np.testing.assert_allclose(p.sum(dim=(1, 2)).numpy(), 1.0, rtol=1e-6)
+    np.testing.assert_allclose(ops.softargmax2d(h).numpy(), 0.5, atol=1e-6)
+
+
+def test_softmax_alpha_temperature():
+    rng = np.random.default_rng(1)
+    h = torch.from_numpy(rng.standard_normal((1, 8, 8, 2)).astype(np.float32))
+    a = ops.channel_softmax_2d(h, alpha=3.0)
+    b = ops.channel_softmax_2d(3.0 * h)
+    np.testing.assert_allclose(a.numpy(), b.numpy(), rtol=1e-6)
+
+
+def test_joint_probability_is_max_of_2x2_window_sums():
+    x = torch.zeros(1, 4, 4, 2)
+    x[0, 1, 1, 0] = 1.0
+    x[0, 1, 2, 0] = 2.0
+    x[0, 2, 1, 0] = 3.0
+    x[0, 2, 2, 0] = 4.0
+    x[0, 3, 3, 1] = 7.0     # bottom-right corner pixel: only one window contains it
+    v = ops.joints_probability(x).numpy()[0, :, 0]
+    np.testing.assert_allclose(v, [10.0, 7.0])
+
+
+def test_context_aggregation_weights_and_grouping():
+    # 2 joints x 2 contexts; contexts of joint j are channels 2j, 2j+1 (blocks.py:229-231)
+    ys = torch.tensor([[[0.2, 0.4], [0.6, 0.8]]])
+    yc = torch.tensor([[[0.0, 0.0], [1.0, 1.0], [0.5, 0.25], [0.5, 0.75]]])
+    pc = torch.tensor([[[1.0], [3.0], [2.0], [2.0]]])
+    y = ops.context_aggregation(ys, yc, pc, 2, 2, alpha=0.8).numpy()[0]
+    np.testing.assert_allclose(y[0], 0.8 * np.array([0.2, 0.4]) + 0.2 * np.array([0.75, 0.75]), rtol=1e-6)
+    np.testing.assert_allclose(y[1], 0.8 * np.array([0.6, 0.8]) + 0.2 * np.array([0.5, 0.5]), rtol=1e-6)
+
+
+def test_softargmax1d_grid_is_pixel_centred():
+    D, J = 16, 3
+    hz = torch.full((1, D, J), -1e4)
+    hz[0, 0, 0] = 0.0
+    hz[0, D - 1, 1] = 0.0
+    hz[0, 5, 2] = 0.0
+    z = ops.softargmax1d(hz).numpy()[0, :, 0]
+    np.testing.assert_allclose(z, [1 / (2 * D), 1 - 1 / (2 * D), (2 * 5 + 1) / (2 * D)], atol=1e-6)
+
+
+def test_kronecker_and_maxmin_pooling():
+    rng = np.random.default_rng(2)
+    hm = torch.from_numpy(rng.random((2, 3, 4, 4, 5)).astype(np.float32))
+    x = torch.from_numpy(rng.standard_normal((2, 3, 4, 4, 7)).astype(np.float32))
+    f = ops.kronecker_prod(hm, x).numpy()
+    ref = (hm.numpy()[..., :, None] * x.numpy()[..., None, :]).sum(axis=(2, 3))
+    np.testing.assert_allclose(f, ref, rtol=1e-5, atol=1e-5)
+    t = torch.from_numpy(rng.standard_normal((1, 5, 6, 2)).astype(np.float32))
+    mm = ops.max_min_pooling(t).numpy()
+    assert mm.shape == (1, 3, 3, 2)
+    np.testing.assert_allclose(mm[0, 0, 0], t[0, :2, :2].amax(dim=(0, 1)).numpy() + t[0, :2, :2].amin(dim=(0, 1)).numpy(),
+                               rtol=1e-6)
+    g = ops.global_max_min_pooling(t).numpy()
+    np.testing.assert_allclose(g[0], t[0].amax(dim=(0, 1)).numpy() + t[0].amin(dim=(0, 1)).numpy(), rtol=1e-6)
+
+
+# ---- second, independent statement (NumPy fp64 loops) of the decoder --------------------------------------
+
+def _np_decoder(h, alpha):
+    F, H, W, C = h.shape
+    h = h.astype(np.float64)
+    xy = np.zeros((F, C, 2))
+    conf = np.zeros((F, C))
+    gx = np.linspace(0, 1, W).astype(np.float32).astype(np.float64)
+    gy = np.linspace(0, 1, H).astype(np.float32).astype(np.float64)
+    for f in range(F):
+        for c in range(C):
+            m = alpha * h[f, :, :, c]
+            e = np.exp(m - m.max())
+            p = e / max(e.sum(), 1e-7)
+            xy[f, c, 0] = (p * gx[None, :]).sum()
+            xy[f, c, 1] = (p * gy[:, None]).sum()
+            raw = h[f, :, :, c]
+            win = raw[:-1, :-1] + raw[:-1, 1:] + raw[1:, :-1] + raw[1:, 1:]
+            conf[f, c] = win.max()
+    return xy, conf
+
+
+def test_torch_oracle_agrees_with_numpy_fp64_decoder():
+    rng = np.random.default_rng(3)
+    h = (rng.standard_normal((2, 32, 32, 6)) * 4).astype(np.float32)
+    xy_np, conf_np = _np_decoder(h, alpha=1.0)
+    t = torch.from_numpy(h)
+    np.testing.assert_allclose(ops.softargmax2d(t).numpy(), xy_np, atol=2e-6)
+    np.testing.assert_allclose(ops.joints_probability(t).numpy()[..., 0], conf_np, rtol=1e-5, atol=1e-5)
+    t64 = t.double()
+    np.testing.assert_allclose(ops.softargmax2d(t64).numpy(), xy_np, atol=1e-12)
