@@ -90,6 +90,15 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
+    # PyTorch-ROCm bundles its own HIP runtime (torch/lib/libamdhip64.so, a different SONAME from the system
+    # libamdhip64.so.7 this library links against).  Streams and device pointers only mean something inside
+    # ONE runtime, so torch must be in the process (its runtime in the global symbol scope) before this
+    # library is loaded; loaded the other way round the two runtimes coexist and every launch on a torch
+    # stream fails.  A host without torch simply gets the system runtime.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     if not os.path.exists(LIB_PATH):
         raise DeepharHipError(
             'libdeephar_hip.so not found at %s -- the HIP back-end is mandatory (no CPU fallback). '

@@ -27,7 +27,7 @@ constexpr int BK = 32;
 constexpr int LDA = BK + 4;  // floats; 144 B rows keep ds_read_b128 conflict-free (odd multiple of 16 B)
 
 template <int WM, int WN, int TM, int TN, bool VEC4, bool UP2>
-__global__ __launch_bounds__(WM* WN * 64, 2) void conv_igemm_kernel(const ConvArgs p) {
+__global__ __launch_bounds__(WM* WN * 64, 2) void conv_igemm_kernel(const ConvArgs p, const int epi_vec) {
   constexpr int NT = WM * WN * 64;
   constexpr int BM = WM * TM * 32;
   constexpr int BN = WN * TN * 32;
@@ -82,86 +82,112 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void conv_igemm_kernel(const ConvAr
 
   const float4* __restrict__ w4 = reinterpret_cast<const float4*>(p.w);
   const int nk = p.Kp / BK;
+  const bool has_pre = p.pre_scale != nullptr;
 
+  // B columns handled by this thread are fixed over the K loop
+  int b_off[BPASS];
+  unsigned bmask = 0;
+#pragma unroll
+  for (int q = 0; q < BPASS; ++q) {
+    const int idx = tid + q * NT;
+    const int kq = idx / BN, j = idx - kq * BN;
+    const bool ok = n0 + j < p.Np;
+    b_off[q] = kq * p.Np + (ok ? n0 + j : 0);
+    bmask |= (ok ? 1u : 0u) << q;
+  }
+
+  // Raw register staging: loads are issued unconditionally (clamped addresses) so that nothing waits on
+  // them until store_tile(), i.e. until after the MFMA block of the current K-step.
   float4 ra[APASS], rb[BPASS];
+  float4 psc = make_float4(1.f, 1.f, 1.f, 1.f), psh = make_float4(0.f, 0.f, 0.f, 0.f);
+  unsigned amask = 0;   // VEC4: bit ps ; scalar path: bit (ps*4 + e)
+
+  // running decode of this thread's k index (k = kt*32 + a_col) into (kh, kw, c); VEC4 only
+  int t_c = a_col % p.Cin, t_kw, t_kh;
+  {
+    const int tap = a_col / p.Cin;
+    t_kh = tap / p.KW;
+    t_kw = tap - t_kh * p.KW;
+  }
 
   auto load_tile = [&](int kt) {
-    const int k0 = kt * BK + a_col;
+    amask = 0;
     if constexpr (VEC4) {
-      const int tap = k0 / p.Cin;
-      const int c = k0 - tap * p.Cin;
-      const int kh = tap / p.KW, kw = tap - kh * p.KW;
-      const bool kvalid = k0 < p.K;
-      float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (p.pre_scale != nullptr && kvalid) {
-        sc = *reinterpret_cast<const float4*>(p.pre_scale + c);
-        sh = *reinterpret_cast<const float4*>(p.pre_shift + c);
+      const bool kvalid = kt * BK + a_col < p.K;
+      if (has_pre) {
+        psc = *reinterpret_cast<const float4*>(p.pre_scale + t_c);
+        psh = *reinterpret_cast<const float4*>(p.pre_shift + t_c);
       }
 #pragma unroll
       for (int ps = 0; ps < APASS; ++ps) {
-        const int ih = a_ih0[ps] + kh, iw = a_iw0[ps] + kw;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (kvalid && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W) {
-          v = *reinterpret_cast<const float4*>(p.x + (size_t)(a_pix[ps] + ih * p.W + iw) * p.ldx + c);
-          if (p.pre_scale != nullptr) {
-            v.x = v.x * sc.x + sh.x; v.y = v.y * sc.y + sh.y;
-            v.z = v.z * sc.z + sh.z; v.w = v.w * sc.w + sh.w;
-          }
-          if (p.pre_relu) {
-            v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
-          }
-        }
-        ra[ps] = v;
+        const int ih = a_ih0[ps] + t_kh, iw = a_iw0[ps] + t_kw;
+        const bool ok = kvalid && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
+        const size_t off = ok ? (size_t)(a_pix[ps] + ih * p.W + iw) * p.ldx + t_c : 0;
+        ra[ps] = *reinterpret_cast<const float4*>(p.x + off);
+        amask |= (ok ? 1u : 0u) << ps;
+      }
+      // advance to the next K-step
+      t_c += BK;
+      while (t_c >= p.Cin) {
+        t_c -= p.Cin;
+        if (++t_kw == p.KW) { t_kw = 0; ++t_kh; }
       }
     } else {
-      int kh[4], kw[4], cc[4];
-      bool kv[4];
+      const int k0 = kt * BK + a_col;
       float sc[4], sh[4];
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         const int k = k0 + e;
         const int tap = k / p.Cin;
-        cc[e] = k - tap * p.Cin;
-        kh[e] = tap / p.KW;
-        kw[e] = tap - kh[e] * p.KW;
-        kv[e] = k < p.K;
-        sc[e] = 1.f; sh[e] = 0.f;
-        if (p.pre_scale != nullptr && kv[e]) { sc[e] = p.pre_scale[cc[e]]; sh[e] = p.pre_shift[cc[e]]; }
-      }
+        const int cc = k - tap * p.Cin;
+        const int kh = tap / p.KW, kw = tap - kh * p.KW;
+        const bool kv = k < p.K;
+        sc[e] = has_pre ? p.pre_scale[cc] : 1.f;
+        sh[e] = has_pre ? p.pre_shift[cc] : 0.f;
 #pragma unroll
-      for (int ps = 0; ps < APASS; ++ps) {
-        float v[4];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const int ih = a_ih0[ps] + kh[e], iw = a_iw0[ps] + kw[e];
-          float t = 0.f;
-          if (kv[e] && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W) {
-            t = p.x[(size_t)(a_pix[ps] + ih * p.W + iw) * p.ldx + cc[e]];
-            if (p.pre_scale != nullptr) t = t * sc[e] + sh[e];
-            if (p.pre_relu) t = fmaxf(t, 0.f);
-          }
-          v[e] = t;
+        for (int ps = 0; ps < APASS; ++ps) {
+          const int ih = a_ih0[ps] + kh, iw = a_iw0[ps] + kw;
+          const bool ok = kv && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
+          const size_t off = ok ? (size_t)(a_pix[ps] + ih * p.W + iw) * p.ldx + cc : 0;
+          (&ra[ps].x)[e] = p.x[off];
+          amask |= (ok ? 1u : 0u) << (ps * 4 + e);
         }
-        ra[ps] = make_float4(v[0], v[1], v[2], v[3]);
       }
+      psc = make_float4(sc[0], sc[1], sc[2], sc[3]);
+      psh = make_float4(sh[0], sh[1], sh[2], sh[3]);
     }
 #pragma unroll
-    for (int q = 0; q < BPASS; ++q) {
-      const int idx = tid + q * NT;
-      const int kq = idx / BN, j = idx - kq * BN;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (n0 + j < p.Np) v = w4[(size_t)(kt * 8 + kq) * p.Np + n0 + j];
-      rb[q] = v;
-    }
+    for (int q = 0; q < BPASS; ++q) rb[q] = w4[(size_t)kt * 8 * p.Np + b_off[q]];
   };
 
   auto store_tile = [&]() {
 #pragma unroll
-    for (int ps = 0; ps < APASS; ++ps)
-      *reinterpret_cast<float4*>(&sA[((tid >> 3) + ps * AROWS) * LDA + a_col]) = ra[ps];
+    for (int ps = 0; ps < APASS; ++ps) {
+      float4 v = ra[ps];
+      if (has_pre) {
+        v.x = v.x * psc.x + psh.x; v.y = v.y * psc.y + psh.y;
+        v.z = v.z * psc.z + psh.z; v.w = v.w * psc.w + psh.w;
+      }
+      if (p.pre_relu) {
+        v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+      }
+      if constexpr (VEC4) {
+        if (!((amask >> ps) & 1u)) v = make_float4(0.f, 0.f, 0.f, 0.f);
+      } else {
+        const unsigned mk = amask >> (ps * 4);
+        if (!(mk & 1u)) v.x = 0.f;
+        if (!(mk & 2u)) v.y = 0.f;
+        if (!(mk & 4u)) v.z = 0.f;
+        if (!(mk & 8u)) v.w = 0.f;
+      }
+      *reinterpret_cast<float4*>(&sA[((tid >> 3) + ps * AROWS) * LDA + a_col]) = v;
+    }
 #pragma unroll
-    for (int q = 0; q < BPASS; ++q)
-      *reinterpret_cast<float4*>(&sB[(tid + q * NT) * 4]) = rb[q];
+    for (int q = 0; q < BPASS; ++q) {
+      float4 v = rb[q];
+      if (!((bmask >> q) & 1u)) v = make_float4(0.f, 0.f, 0.f, 0.f);
+      *reinterpret_cast<float4*>(&sB[(tid + q * NT) * 4]) = v;
+    }
   };
 
   f32x16 acc[TM][TN];
@@ -206,37 +232,77 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void conv_igemm_kernel(const ConvAr
     }
   }
 
-  // ---- epilogue: C/D layout of the 32x32 tile: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+  // ---- epilogue.  C/D layout of a 32x32 tile: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).
+  // Each wave stages one 32 x (TN*32) row block through its private LDS slab and reads it back row-wise, so
+  // the BN affine / residual loads / stores are 16-byte wide and whole output rows are contiguous.
+  constexpr int LDC = TN * 32 + 4;
+  constexpr int ROW4 = TN * 8;                 // float4 per staged row
+  float* sC = smem + wave * 32 * LDC;
   const int ohw = p.OH * p.OW;
+  const bool vec = epi_vec != 0;
 #pragma unroll
-  for (int j = 0; j < TN; ++j) {
-    const int n = n0 + (wn * TN + j) * 32 + li;
-    if (n >= p.Cout) continue;
-    float sc = 1.f, sh = 0.f;
-    if (p.post_scale != nullptr) { sc = p.post_scale[n]; sh = p.post_shift[n]; }
+  for (int i = 0; i < TM; ++i) {
+    __syncthreads();
 #pragma unroll
-    for (int i = 0; i < TM; ++i) {
+    for (int j = 0; j < TN; ++j)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int m = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-        if (m >= M) continue;
-        float v = acc[i][j][r] * sc + sh;
-        if (p.res1 != nullptr) v += p.res1[(size_t)m * p.ldr1 + n];
-        if constexpr (!UP2) {
-          if (p.res2 != nullptr) v += p.res2[(size_t)m * p.ldr2 + n];
-          if (p.post_relu) v = fmaxf(v, 0.f);
-          p.y[(size_t)m * p.ldy + n] = v;
-        } else {
-          const int f = m / ohw;
-          const int rem = m - f * ohw;
-          const int oh = rem / p.OW, ow = rem - oh * p.OW;
+      for (int r = 0; r < 16; ++r)
+        sC[((r & 3) + 8 * (r >> 2) + 4 * lh) * LDC + j * 32 + li] = acc[i][j][r];
+    __syncthreads();
+#pragma unroll 2
+    for (int f = lane; f < 32 * ROW4; f += 64) {
+      const int row = f / ROW4, c4 = f - row * ROW4;
+      const int m = m0 + (wm * TM + i) * 32 + row;
+      const int n = n0 + wn * TN * 32 + c4 * 4;
+      if (m >= M || n >= p.Cout) continue;
+      float4 v = *reinterpret_cast<const float4*>(&sC[row * LDC + c4 * 4]);
+      size_t mo[4];
+      int nout = 1;
+      if constexpr (UP2) {
+        const int fr = m / ohw;
+        const int rem = m - fr * ohw;
+        const int oh = rem / p.OW, ow = rem - oh * p.OW;
 #pragma unroll
-          for (int d = 0; d < 4; ++d) {
-            const size_t mo = ((size_t)f * 2 * p.OH + 2 * oh + (d >> 1)) * (2 * p.OW) + 2 * ow + (d & 1);
-            float o = v;
-            if (p.res2 != nullptr) o += p.res2[mo * p.ldr2 + n];
+        for (int d = 0; d < 4; ++d)
+          mo[d] = ((size_t)fr * 2 * p.OH + 2 * oh + (d >> 1)) * (2 * p.OW) + 2 * ow + (d & 1);
+        nout = 4;
+      } else {
+        mo[0] = (size_t)m;
+      }
+      if (vec) {
+        if (p.post_scale != nullptr) {
+          const float4 sc = *reinterpret_cast<const float4*>(p.post_scale + n);
+          const float4 sh = *reinterpret_cast<const float4*>(p.post_shift + n);
+          v.x = v.x * sc.x + sh.x; v.y = v.y * sc.y + sh.y; v.z = v.z * sc.z + sh.z; v.w = v.w * sc.w + sh.w;
+        }
+        if (p.res1 != nullptr) {
+          const float4 r = *reinterpret_cast<const float4*>(p.res1 + (size_t)m * p.ldr1 + n);
+          v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
+        }
+#pragma unroll
+        for (int d = 0; d < (UP2 ? 4 : 1); ++d) {
+          float4 o = v;
+          if (p.res2 != nullptr) {
+            const float4 r = *reinterpret_cast<const float4*>(p.res2 + mo[d] * p.ldr2 + n);
+            o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w;
+          }
+          if (p.post_relu) {
+            o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f);
+          }
+          *reinterpret_cast<float4*>(p.y + mo[d] * p.ldy + n) = o;
+        }
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          if (n + e >= p.Cout) break;
+          float t = (&v.x)[e];
+          if (p.post_scale != nullptr) t = t * p.post_scale[n + e] + p.post_shift[n + e];
+          if (p.res1 != nullptr) t += p.res1[(size_t)m * p.ldr1 + n + e];
+          for (int d = 0; d < nout; ++d) {
+            float o = t;
+            if (p.res2 != nullptr) o += p.res2[mo[d] * p.ldr2 + n + e];
             if (p.post_relu) o = fmaxf(o, 0.f);
-            p.y[mo * p.ldy + n] = o;
+            p.y[mo[d] * p.ldy + n + e] = o;
           }
         }
       }
@@ -264,16 +330,22 @@ int launch_cfg(const ConvArgs& a, bool vec4, hipStream_t s) {
   const long long M = (long long)a.N * a.OH * a.OW;
   const long long tiles = ((M + BM - 1) / BM) * ((a.Cout + BN - 1) / BN);
   if (tiles <= 0 || tiles > 0x7fffffffLL) return DH_EINVAL;
-  const size_t lds = (size_t)(BM * LDA + BK * BN) * sizeof(float);
+  auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
+  const int epi = (a.Cout % 4 == 0) && (a.ldy % 4 == 0) && al16(a.y) &&
+                  (a.res1 == nullptr || (a.ldr1 % 4 == 0 && al16(a.res1))) &&
+                  (a.res2 == nullptr || (a.ldr2 % 4 == 0 && al16(a.res2))) &&
+                  (a.post_scale == nullptr || (al16(a.post_scale) && al16(a.post_shift)));
+  constexpr int kStage = BM * LDA + BK * BN, kEpi = WM * WN * 32 * (TN * 32 + 4);
+  const size_t lds = (size_t)(kStage > kEpi ? kStage : kEpi) * sizeof(float);
   if (a.up2) {
     if (!vec4) return DH_EUNSUPPORTED;
     if constexpr (TM * TN >= 6) return DH_EUNSUPPORTED;  // would spill; the dispatcher never asks for it
     else
-    hipLaunchKernelGGL((conv_igemm_kernel<WM, WN, TM, TN, true, true>), dim3((unsigned)tiles), dim3(NT), lds, s, a);
+    hipLaunchKernelGGL((conv_igemm_kernel<WM, WN, TM, TN, true, true>), dim3((unsigned)tiles), dim3(NT), lds, s, a, epi);
   } else if (vec4) {
-    hipLaunchKernelGGL((conv_igemm_kernel<WM, WN, TM, TN, true, false>), dim3((unsigned)tiles), dim3(NT), lds, s, a);
+    hipLaunchKernelGGL((conv_igemm_kernel<WM, WN, TM, TN, true, false>), dim3((unsigned)tiles), dim3(NT), lds, s, a, epi);
   } else {
-    hipLaunchKernelGGL((conv_igemm_kernel<WM, WN, TM, TN, false, false>), dim3((unsigned)tiles), dim3(NT), lds, s, a);
+    hipLaunchKernelGGL((conv_igemm_kernel<WM, WN, TM, TN, false, false>), dim3((unsigned)tiles), dim3(NT), lds, s, a, epi);
   }
   return check_launch();
 }
@@ -282,23 +354,18 @@ int launch_cfg(const ConvArgs& a, bool vec4, hipStream_t s) {
 
 int conv_igemm_num_cfgs() { return kNumCfgs; }
 
-// Heuristic: widest BN that wastes < ~12% of the padded N, then the largest BM that still yields
-// >= 2 workgroups per CU (256 CUs) if possible.
+// Default tiling when the caller does not autotune (measured on MI355X, tools/bench_ops.py): four waves
+// side by side along M with narrow per-wave tiles (more resident waves per SIMD) beat the 2x2-wave layouts;
+// memory/epilogue-bound shapes (tiny K or tiny M) want the narrowest tile.
 int conv_igemm_pick_cfg(int M, int Cout) {
   const int np = (Cout + 31) / 32 * 32;
-  auto waste = [&](int bn) { return (double)(((np + bn - 1) / bn) * bn - np) / np; };
-  int bn;
-  if (waste(192) < 0.12) bn = 192;
-  else if (waste(128) < 0.12) bn = 128;
-  else if (waste(96) < 0.12) bn = 96;
-  else if (waste(64) < 0.12) bn = 64;
-  else bn = 32;
-  auto blocks = [&](int bm, int bnn) { return (long long)((M + bm - 1) / bm) * ((np + bnn - 1) / bnn); };
-  if (bn == 192) { if (blocks(128, 192) >= 384) return 0; bn = 96; }
-  if (bn == 128) { if (blocks(128, 128) >= 384) return 1; bn = 64; }
-  if (bn == 96) { if (blocks(128, 96) >= 384) return 2; return 5; }
-  if (bn == 64) { if (blocks(128, 64) >= 384) return 3; return 6; }
-  if (blocks(128, 32) >= 384) return 4;
+  auto blocks = [&](int bm, int bn) { return (long long)((M + bm - 1) / bm) * ((np + bn - 1) / bn); };
+  int bn = 32;
+  if (np % 96 == 0) bn = 96;
+  else if (np % 64 == 0) bn = 64;
+  if (bn == 96) return blocks(128, 96) >= 512 ? 2 : (blocks(128, 32) >= 512 ? 4 : 7);
+  if (bn == 64) return blocks(128, 64) >= 512 ? 3 : (blocks(128, 32) >= 512 ? 4 : 7);
+  if (blocks(128, 32) >= 512) return 4;
   if (blocks(64, 32) >= 256) return 7;
   return 8;
 }

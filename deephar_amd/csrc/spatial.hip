@@ -24,11 +24,12 @@ __device__ __forceinline__ float4 min4(float4 a, float4 b) {
 // Depthwise conv.  Thread = (channel quad, output row, strip of TW output columns).  The strip walks a
 // sliding window along W so each input float4 is loaded once per (row, kh) instead of KW times.
 // ------------------------------------------------------------------------------------------------
-template <int KW, int TW>
+template <int KS, int TW>
 __global__ __launch_bounds__(256) void dwconv_kernel(const DwArgs p) {
   const int c4n = p.C >> 2;
   const int strips = (p.W + TW - 1) / TW;
   const long long total = (long long)p.N * p.H * strips * c4n;
+  const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
   for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
        idx += (long long)gridDim.x * blockDim.x) {
     const int c = (int)(idx % c4n) * 4;
@@ -38,32 +39,39 @@ __global__ __launch_bounds__(256) void dwconv_kernel(const DwArgs p) {
     const int n = (int)(t / p.H);
     const int ow0 = st * TW;
 
-    float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f);
     const bool aff = p.pre_scale != nullptr;
+    float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = zero;
     if (aff) { sc = ld4(p.pre_scale + c); sh = ld4(p.pre_shift + c); }
 
     float4 acc[TW];
 #pragma unroll
-    for (int i = 0; i < TW; ++i) acc[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int i = 0; i < TW; ++i) acc[i] = zero;
 
-    for (int kh = 0; kh < p.KH; ++kh) {
+#pragma unroll 1
+    for (int kh = 0; kh < KS; ++kh) {   // one row of taps at a time keeps ~110 VGPRs (4 waves/SIMD)
       const int ih = oh - p.PT + kh;
-      if ((unsigned)ih >= (unsigned)p.H) continue;
-      const float* row = p.x + ((size_t)(n * p.H + ih) * p.W) * p.ldx + c;
-      float4 wv[KW];
+      const bool rok = (unsigned)ih < (unsigned)p.H;
+      const float* row = p.x + ((size_t)(n * p.H + (rok ? ih : 0)) * p.W) * p.ldx + c;
+      // all loads of the row are issued unconditionally (clamped), masked afterwards: no wait between them
+      float4 in[TW + KS - 1];
 #pragma unroll
-      for (int kw = 0; kw < KW; ++kw) wv[kw] = ld4(p.w + (size_t)(kh * KW + kw) * p.C + c);
-#pragma unroll
-      for (int j = 0; j < TW + KW - 1; ++j) {
+      for (int j = 0; j < TW + KS - 1; ++j) {
         const int iw = ow0 - p.PL + j;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if ((unsigned)iw < (unsigned)p.W) {
-          v = ld4(row + (size_t)iw * p.ldx);
-          if (aff) v = fma4(v, sc, sh);
-          if (p.pre_relu) v = max4(v, make_float4(0.f, 0.f, 0.f, 0.f));
-        }
+        const bool ok = (unsigned)iw < (unsigned)p.W;
+        in[j] = ld4(row + (size_t)(ok ? iw : 0) * p.ldx);
+      }
+      float4 wv[KS];
 #pragma unroll
-        for (int kw = 0; kw < KW; ++kw) {
+      for (int kw = 0; kw < KS; ++kw) wv[kw] = ld4(p.w + (size_t)(kh * KS + kw) * p.C + c);
+#pragma unroll
+      for (int j = 0; j < TW + KS - 1; ++j) {
+        const int iw = ow0 - p.PL + j;
+        float4 v = in[j];
+        if (aff) v = fma4(v, sc, sh);
+        if (p.pre_relu) v = max4(v, zero);
+        if (!(rok && (unsigned)iw < (unsigned)p.W)) v = zero;
+#pragma unroll
+        for (int kw = 0; kw < KS; ++kw) {
           const int o = j - kw;
           if (o >= 0 && o < TW) acc[o] = fma4(v, wv[kw], acc[o]);
         }
@@ -242,12 +250,16 @@ int launch_dwconv(const DwArgs& a, hipStream_t s) {
   if (a.N <= 0 || a.C <= 0 || a.KH <= 0 || a.KW <= 0) return DH_EINVAL;
   const bool vec = (a.C % 4 == 0) && (a.ldx % 4 == 0) && (a.ldy % 4 == 0) && al16(a.x) && al16(a.y) &&
                    al16(a.w) && (a.pre_scale == nullptr || (al16(a.pre_scale) && al16(a.pre_shift)));
-  if (vec && (a.KW == 5 || a.KW == 3 || a.KW == 1)) {
-    constexpr int TW = 4;
+  if (vec && a.KH == a.KW && (a.KW == 5 || a.KW == 3 || a.KW == 1)) {
+    const int TW = a.W >= 16 ? 8 : 4;
     const long long total = (long long)a.N * a.H * ((a.W + TW - 1) / TW) * (a.C / 4);
-    if (a.KW == 5) hipLaunchKernelGGL((dwconv_kernel<5, TW>), dim3(grid_for(total)), dim3(256), 0, s, a);
-    else if (a.KW == 3) hipLaunchKernelGGL((dwconv_kernel<3, TW>), dim3(grid_for(total)), dim3(256), 0, s, a);
-    else hipLaunchKernelGGL((dwconv_kernel<1, TW>), dim3(grid_for(total)), dim3(256), 0, s, a);
+    const dim3 g(grid_for(total)), b(256);
+    if (a.KW == 5 && TW == 8) hipLaunchKernelGGL((dwconv_kernel<5, 8>), g, b, 0, s, a);
+    else if (a.KW == 5) hipLaunchKernelGGL((dwconv_kernel<5, 4>), g, b, 0, s, a);
+    else if (a.KW == 3 && TW == 8) hipLaunchKernelGGL((dwconv_kernel<3, 8>), g, b, 0, s, a);
+    else if (a.KW == 3) hipLaunchKernelGGL((dwconv_kernel<3, 4>), g, b, 0, s, a);
+    else if (TW == 8) hipLaunchKernelGGL((dwconv_kernel<1, 8>), g, b, 0, s, a);
+    else hipLaunchKernelGGL((dwconv_kernel<1, 4>), g, b, 0, s, a);
   } else {
     const long long total = (long long)a.N * a.H * a.W * a.C;
     hipLaunchKernelGGL(dwconv_generic_kernel, dim3(grid_for(total)), dim3(256), 0, s, a);

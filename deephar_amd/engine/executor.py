@@ -296,6 +296,52 @@ class BoundPlan:
     def replay(self, stream_ptr):
         _lib.check(self.lib.dh_graph_launch(self.graph, stream_ptr), 'graph launch')
 
+    # ---- autotuning of the conv tiling -------------------------------------------------------------------
+    @staticmethod
+    def _conv_signature(step):
+        a, x, y = step.attrs, step.ins['x'], step.outs['y']
+        return (x.lead(3), x.shape[-3], x.shape[-2], x.C, x.ld, y.ld, a['Cout'], a['kh'], a['kw'], a['sh'],
+                a['sw'], a['pre_relu'], a['post_relu'], a['up2'], 'res1' in step.ins, 'res2' in step.ins,
+                'pre_bn' in step.params, 'post_bn' in step.params)
+
+    def autotune(self, stream_ptr, table=None, reps=3):
+        """Time every tile configuration of dh_conv2d_f32 for each distinct conv shape of this bound plan
+        (HIP events on the launch stream) and keep the fastest.  All configurations sum K in the same order,
+        so the choice never changes a result bit.  `table` (signature -> cfg) is filled / reused."""
+        lib = self.lib
+        table = {} if table is None else table
+        ncfg = lib.dh_conv2d_num_tile_cfgs()
+        e0, e1 = C.c_void_p(), C.c_void_p()
+        _lib.check(lib.dh_event_create(C.byref(e0)))
+        _lib.check(lib.dh_event_create(C.byref(e1)))
+        for i, (fn, args, step) in enumerate(self.calls):
+            if step.kind != 'conv':
+                continue
+            sig = (self.n,) + self._conv_signature(step)
+            if sig not in table:
+                best, best_ms = -1, float('inf')
+                for cfg in range(ncfg):
+                    if fn(args[0], cfg, stream_ptr) != 0:     # unsupported combination (warm-up launch)
+                        continue
+                    _lib.check(lib.dh_event_record(e0, stream_ptr))
+                    for _ in range(reps):
+                        fn(args[0], cfg, stream_ptr)
+                    _lib.check(lib.dh_event_record(e1, stream_ptr))
+                    _lib.check(lib.dh_event_synchronize(e1))
+                    ms = C.c_float()
+                    _lib.check(lib.dh_event_elapsed_ms(e0, e1, C.byref(ms)))
+                    if ms.value < best_ms:
+                        best, best_ms = cfg, ms.value
+                table[sig] = best
+            step.attrs['tile_cfg'] = table[sig]
+            self.calls[i] = (fn, (args[0], table[sig]), step)
+        lib.dh_event_destroy(e0)
+        lib.dh_event_destroy(e1)
+        if self.graph is not None:
+            lib.dh_graph_destroy(self.graph)
+            self.graph = None
+        return table
+
     def profile(self, stream_ptr, reps=1):
         """Per-step device time (ms, mean over reps) with HIP events recorded on the launch stream."""
         lib = self.lib
@@ -328,7 +374,7 @@ class BoundPlan:
 
 
 class Executor:
-    def __init__(self, plan, device=None, use_graph=True):
+    def __init__(self, plan, device=None, use_graph=True, autotune=True):
         torch = _torch()
         if not torch.cuda.is_available():
             raise _lib.DeepharHipError('no HIP device visible: deephar_amd runs only on an AMD GPU (gfx950); '
@@ -337,6 +383,8 @@ class Executor:
         self.device = torch.device(device or 'cuda:%d' % torch.cuda.current_device())
         self.plan = plan
         self.use_graph = use_graph
+        self.autotune = autotune
+        self.tune_table = {}
         self.store = WeightStore(self.device)
         self.bound = {}
         with torch.cuda.device(self.device):
@@ -352,6 +400,8 @@ class Executor:
             torch = _torch()
             with torch.cuda.device(self.device), torch.cuda.stream(self.stream):
                 bp = BoundPlan(self.plan, n, self.store, self.device)
+                if self.autotune:
+                    bp.autotune(self.stream_ptr, self.tune_table)
             self.bound[n] = bp
         return bp
 

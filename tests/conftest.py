@@ -9,6 +9,11 @@ if ROOT not in sys.path:
 
 
 def pytest_configure(config):
+    try:   # the CPU oracle (PyTorch-CPU) is slower, not faster, with hundreds of threads on the GPU box
+        import torch
+        torch.set_num_threads(min(os.cpu_count() or 1, 32))
+    except ImportError:
+        pass
     config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu on the GPU box)')
 
 
