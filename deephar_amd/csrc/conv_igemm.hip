@@ -15,11 +15,9 @@
 //   A b128 fragment read hands each lane 4 consecutive k; MFMA t consumes element t of both operands, so
 //   the lane halves (k, k+4) pair up -- a permutation of the K order, which the sum does not care about.
 //   blockIdx is remapped so that the N-tiles sharing one A tile run back to back on the same XCD (L2).
-#include "dh_kernels.h"
+#include "conv_common.h"
 
 namespace dh {
-
-typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 namespace {
 
@@ -49,14 +47,7 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void conv_igemm_kernel(const ConvAr
   const int M = p.N * p.OH * p.OW;
   const int tiles_n = (p.Cout + BN - 1) / BN;
 
-  // XCD-aware bijective remap: block b runs on XCD b%8; give each XCD a contiguous run of tiles so the
-  // tiles_n workgroups that share one activation tile hit the same L2.
-  int tile;
-  {
-    const int nwg = gridDim.x, b = blockIdx.x;
-    const int xcd = b & 7, q = nwg >> 3, r = nwg & 7;
-    tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
-  }
+  const int tile = xcd_tile(blockIdx.x, gridDim.x);
   const int m0 = (tile / tiles_n) * BM;
   const int n0 = (tile % tiles_n) * BN;
 
@@ -232,82 +223,7 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void conv_igemm_kernel(const ConvAr
     }
   }
 
-  // ---- epilogue.  C/D layout of a 32x32 tile: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).
-  // Each wave stages one 32 x (TN*32) row block through its private LDS slab and reads it back row-wise, so
-  // the BN affine / residual loads / stores are 16-byte wide and whole output rows are contiguous.
-  constexpr int LDC = TN * 32 + 4;
-  constexpr int ROW4 = TN * 8;                 // float4 per staged row
-  float* sC = smem + wave * 32 * LDC;
-  const int ohw = p.OH * p.OW;
-  const bool vec = epi_vec != 0;
-#pragma unroll
-  for (int i = 0; i < TM; ++i) {
-    __syncthreads();
-#pragma unroll
-    for (int j = 0; j < TN; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r)
-        sC[((r & 3) + 8 * (r >> 2) + 4 * lh) * LDC + j * 32 + li] = acc[i][j][r];
-    __syncthreads();
-#pragma unroll 2
-    for (int f = lane; f < 32 * ROW4; f += 64) {
-      const int row = f / ROW4, c4 = f - row * ROW4;
-      const int m = m0 + (wm * TM + i) * 32 + row;
-      const int n = n0 + wn * TN * 32 + c4 * 4;
-      if (m >= M || n >= p.Cout) continue;
-      float4 v = *reinterpret_cast<const float4*>(&sC[row * LDC + c4 * 4]);
-      size_t mo[4];
-      int nout = 1;
-      if constexpr (UP2) {
-        const int fr = m / ohw;
-        const int rem = m - fr * ohw;
-        const int oh = rem / p.OW, ow = rem - oh * p.OW;
-#pragma unroll
-        for (int d = 0; d < 4; ++d)
-          mo[d] = ((size_t)fr * 2 * p.OH + 2 * oh + (d >> 1)) * (2 * p.OW) + 2 * ow + (d & 1);
-        nout = 4;
-      } else {
-        mo[0] = (size_t)m;
-      }
-      if (vec) {
-        if (p.post_scale != nullptr) {
-          const float4 sc = *reinterpret_cast<const float4*>(p.post_scale + n);
-          const float4 sh = *reinterpret_cast<const float4*>(p.post_shift + n);
-          v.x = v.x * sc.x + sh.x; v.y = v.y * sc.y + sh.y; v.z = v.z * sc.z + sh.z; v.w = v.w * sc.w + sh.w;
-        }
-        if (p.res1 != nullptr) {
-          const float4 r = *reinterpret_cast<const float4*>(p.res1 + (size_t)m * p.ldr1 + n);
-          v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
-        }
-#pragma unroll
-        for (int d = 0; d < (UP2 ? 4 : 1); ++d) {
-          float4 o = v;
-          if (p.res2 != nullptr) {
-            const float4 r = *reinterpret_cast<const float4*>(p.res2 + mo[d] * p.ldr2 + n);
-            o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w;
-          }
-          if (p.post_relu) {
-            o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f);
-          }
-          *reinterpret_cast<float4*>(p.y + mo[d] * p.ldy + n) = o;
-        }
-      } else {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          if (n + e >= p.Cout) break;
-          float t = (&v.x)[e];
-          if (p.post_scale != nullptr) t = t * p.post_scale[n + e] + p.post_shift[n + e];
-          if (p.res1 != nullptr) t += p.res1[(size_t)m * p.ldr1 + n + e];
-          for (int d = 0; d < nout; ++d) {
-            float o = t;
-            if (p.res2 != nullptr) o += p.res2[mo[d] * p.ldr2 + n + e];
-            if (p.post_relu) o = fmaxf(o, 0.f);
-            p.y[mo[d] * p.ldy + n + e] = o;
-          }
-        }
-      }
-    }
-  }
+  conv_epilogue<WM, WN, TM, TN, UP2>(p, acc, smem, m0, n0, M, epi_vec);
 }
 
 struct Cfg { int wm, wn, tm, tn; };
@@ -325,16 +241,11 @@ constexpr Cfg kCfgs[] = {
 constexpr int kNumCfgs = sizeof(kCfgs) / sizeof(kCfgs[0]);
 
 template <int WM, int WN, int TM, int TN>
-int launch_cfg(const ConvArgs& a, bool vec4, hipStream_t s) {
+int launch_cfg(const ConvArgs& a, bool vec4, int epi, hipStream_t s) {
   constexpr int BM = WM * TM * 32, BN = WN * TN * 32, NT = WM * WN * 64;
   const long long M = (long long)a.N * a.OH * a.OW;
   const long long tiles = ((M + BM - 1) / BM) * ((a.Cout + BN - 1) / BN);
   if (tiles <= 0 || tiles > 0x7fffffffLL) return DH_EINVAL;
-  auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
-  const int epi = (a.Cout % 4 == 0) && (a.ldy % 4 == 0) && al16(a.y) &&
-                  (a.res1 == nullptr || (a.ldr1 % 4 == 0 && al16(a.res1))) &&
-                  (a.res2 == nullptr || (a.ldr2 % 4 == 0 && al16(a.res2))) &&
-                  (a.post_scale == nullptr || (al16(a.post_scale) && al16(a.post_shift)));
   constexpr int kStage = BM * LDA + BK * BN, kEpi = WM * WN * 32 * (TN * 32 + 4);
   const size_t lds = (size_t)(kStage > kEpi ? kStage : kEpi) * sizeof(float);
   if (a.up2) {
@@ -352,7 +263,11 @@ int launch_cfg(const ConvArgs& a, bool vec4, hipStream_t s) {
 
 }  // namespace
 
-int conv_igemm_num_cfgs() { return kNumCfgs; }
+bool gemm1x1_eligible(const ConvArgs& a);
+int launch_gemm1x1(const ConvArgs& a, int cfg, int epi, hipStream_t s);
+
+// cfg 0..8: general implicit-GEMM kernel; cfg 9..17: the same tile shapes on the LDS-DMA pointwise kernel
+int conv_igemm_num_cfgs() { return 2 * kNumCfgs; }
 
 // Default tiling when the caller does not autotune (measured on MI355X, tools/bench_ops.py): four waves
 // side by side along M with narrow per-wave tiles (more resident waves per SIMD) beat the 2x2-wave layouts;
@@ -376,22 +291,32 @@ int launch_conv_igemm(const ConvArgs& a, int cfg, hipStream_t s) {
     return DH_EINVAL;
   if ((long long)a.N * a.H * a.W > 0x7fffffffLL || (long long)a.N * a.OH * a.OW * (a.up2 ? 4 : 1) > 0x7fffffffLL)
     return DH_EINVAL;
-  if (cfg < 0) cfg = conv_igemm_pick_cfg(a.N * a.OH * a.OW, a.Cout);
-  if (cfg >= kNumCfgs) return DH_EINVAL;
+  if (cfg < 0) cfg = conv_igemm_pick_cfg(a.N * a.OH * a.OW, a.Cout) + (gemm1x1_eligible(a) ? kNumCfgs : 0);
+  if (cfg >= 2 * kNumCfgs) return DH_EINVAL;
+  auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
+  const int epi = (a.Cout % 4 == 0) && (a.ldy % 4 == 0) && al16(a.y) &&
+                  (a.res1 == nullptr || (a.ldr1 % 4 == 0 && al16(a.res1))) &&
+                  (a.res2 == nullptr || (a.ldr2 % 4 == 0 && al16(a.res2))) &&
+                  (a.post_scale == nullptr || (al16(a.post_scale) && al16(a.post_shift)));
+  if (cfg >= kNumCfgs) {
+    cfg -= kNumCfgs;
+    if (a.up2 && cfg == 0) cfg = 2;
+    return launch_gemm1x1(a, cfg, epi, s);
+  }
   if (a.up2 && cfg == 0) cfg = 2;  // 128x192 + fused up-sampling epilogue exceeds the register budget
   const bool vec4 = (a.Cin % 4 == 0) && (a.ldx % 4 == 0) && ((reinterpret_cast<uintptr_t>(a.x) & 15) == 0) &&
                     (a.pre_scale == nullptr || (((reinterpret_cast<uintptr_t>(a.pre_scale) |
                                                   reinterpret_cast<uintptr_t>(a.pre_shift)) & 15) == 0));
   switch (cfg) {
-    case 0: return launch_cfg<2, 2, 2, 3>(a, vec4, s);
-    case 1: return launch_cfg<2, 2, 2, 2>(a, vec4, s);
-    case 2: return launch_cfg<4, 1, 1, 3>(a, vec4, s);
-    case 3: return launch_cfg<4, 1, 1, 2>(a, vec4, s);
-    case 4: return launch_cfg<4, 1, 1, 1>(a, vec4, s);
-    case 5: return launch_cfg<2, 1, 1, 3>(a, vec4, s);
-    case 6: return launch_cfg<2, 1, 1, 2>(a, vec4, s);
-    case 7: return launch_cfg<2, 1, 1, 1>(a, vec4, s);
-    case 8: return launch_cfg<1, 1, 1, 1>(a, vec4, s);
+    case 0: return launch_cfg<2, 2, 2, 3>(a, vec4, epi, s);
+    case 1: return launch_cfg<2, 2, 2, 2>(a, vec4, epi, s);
+    case 2: return launch_cfg<4, 1, 1, 3>(a, vec4, epi, s);
+    case 3: return launch_cfg<4, 1, 1, 2>(a, vec4, epi, s);
+    case 4: return launch_cfg<4, 1, 1, 1>(a, vec4, epi, s);
+    case 5: return launch_cfg<2, 1, 1, 3>(a, vec4, epi, s);
+    case 6: return launch_cfg<2, 1, 1, 2>(a, vec4, epi, s);
+    case 7: return launch_cfg<2, 1, 1, 1>(a, vec4, epi, s);
+    case 8: return launch_cfg<1, 1, 1, 1>(a, vec4, epi, s);
   }
   return DH_EINVAL;
 }

@@ -65,17 +65,40 @@ def test_conv2d_plain(case, hip_lib, cuda):
     assert e_hip <= 4 * e_cpu + 1e-6, (e_hip, e_cpu)
 
 
-@pytest.mark.parametrize('cfg', range(9))
+@pytest.mark.parametrize('cfg', range(18))
 def test_conv2d_every_tile_config(cfg, hip_lib, cuda):
+    """cfg 0..8: general implicit-GEMM kernel (3x3 here); cfg 9..17: the LDS-DMA pointwise kernel (1x1).
+    All tilings must agree bit-for-bit (same K summation order), which is what lets the autotuner pick freely."""
     from deephar_amd import functional as F
-    assert hip_lib.dh_conv2d_num_tile_cfgs() == 9
-    rng = np.random.default_rng(cfg)
-    x = _rand(rng, (2, 19, 23, 96))          # M = 874: ragged in every BM
-    k = _rand(rng, (3, 3, 96, 200), 0.05)    # Cout = 200: ragged in every BN
-    ref = O.conv2d(torch.from_numpy(x), torch.from_numpy(k))
-    got = F.conv2d(torch.from_numpy(x).to(cuda), k, tile_cfg=cfg)
+    assert hip_lib.dh_conv2d_num_tile_cfgs() == 18
+    rng = np.random.default_rng(cfg % 9)
+    ks = 3 if cfg < 9 else 1
+    x = _rand(rng, (2, 19, 23, 96))           # M = 874: ragged in every BM
+    k = _rand(rng, (ks, ks, 96, 200), 0.05)   # Cout = 200: ragged in every BN
+    r1 = _rand(rng, (2, 19, 23, 200))
+    ref = O.conv2d(O.relu(torch.from_numpy(x)), torch.from_numpy(k)) + torch.from_numpy(r1)
+    d = lambda a: torch.from_numpy(a).to(cuda)
+    got = F.conv2d(d(x), k, pre_relu=True, res1=d(r1), tile_cfg=cfg)
+    base = F.conv2d(d(x), k, pre_relu=True, res1=d(r1), tile_cfg=8 if cfg < 9 else 17)
     torch.cuda.synchronize()
     _close(got, ref, atol=3e-5, what='cfg %d' % cfg)
+    assert torch.equal(got, base), 'tilings disagree bitwise'
+
+
+@pytest.mark.parametrize('cin,cout', [(576, 576), (48, 576), (576, 48), (100, 36), (288, 272)])
+def test_pointwise_dma_kernel_matches_general_kernel(cin, cout, hip_lib, cuda):
+    """K tails (k >= K clamped, zero weights), Cout tails and M tails of the LDS-DMA kernel."""
+    from deephar_amd import functional as F
+    rng = np.random.default_rng(cin + cout)
+    x = _rand(rng, (3, 13, 11, cin))
+    k = _rand(rng, (1, 1, cin, cout), np.sqrt(1.0 / cin))
+    d = lambda a: torch.from_numpy(a).to(cuda)
+    a = F.conv2d(d(x), k, pre_relu=True, tile_cfg=3)
+    b = F.conv2d(d(x), k, pre_relu=True, tile_cfg=12)
+    c = F.conv2d(d(x), k, pre_relu=True, tile_cfg=-1)
+    torch.cuda.synchronize()
+    assert torch.equal(a, b) and torch.equal(a, c)
+    _close(a, O.conv2d(O.relu(torch.from_numpy(x)), torch.from_numpy(k)), atol=2e-5, what='pointwise')
 
 
 def test_conv2d_fused_prologue_epilogue(hip_lib, cuda):
@@ -114,7 +137,7 @@ def test_conv2d_prologue_keeps_padding_zero(hip_lib, cuda):
     assert got[0, 3, 3, 0] == 72.0 and got[0, 0, 0, 0] == 32.0 and got[0, 0, 3, 5] == 48.0
 
 
-@pytest.mark.parametrize('cout,cfg', [(288, -1), (576, -1), (96, 5), (64, 1)])
+@pytest.mark.parametrize('cout,cfg', [(288, -1), (576, -1), (96, 5), (64, 1), (576, 11), (288, 13), (96, 9)])
 def test_conv2d_fused_upsample_add(cout, cfg, hip_lib, cuda):
     """conv -> BN -> +res1 -> UpSampling2D -> +res2 (reception.py:122-127) in the conv epilogue."""
     from deephar_amd import functional as F
