@@ -210,6 +210,10 @@ class BoundPlan:
             if 'bn' in s.params:
                 sc, sh = self.store.bn_affine(s.params['bn'])
                 args.scale, args.shift = sc.data_ptr(), sh.data_ptr()
+            elif 'scale_const' in a:
+                kc, cc = a['scale_const'], av.C
+                args.scale = self.store.constant(('const', kc, cc), lambda: np.full(cc, kc, np.float32)).data_ptr()
+                args.shift = self.store.constant(('const', 0.0, cc), lambda: np.zeros(cc, np.float32)).data_ptr()
             args.npix, args.C = n * av.npix, av.C
             args.relu, args.op, args.bcast_b = a.get('relu', 0), a.get('op', 0), a.get('bcast_b', 0)
             self._keep.append(args)

@@ -346,6 +346,13 @@ class Planner:
                   name=node.name or 'mul')
         self.val[node.outputs[0].uid] = y
 
+    def op_scale(self, node):
+        a = self.materialize(node.inputs[0])
+        y = self.out_value_for(node.outputs[0])
+        self.emit('eltwise', dict(a=a), dict(y=y), dict(op=0, relu=0, scale_const=float(node.attrs['k'])),
+                  name=node.name or 'scale')
+        self.val[node.outputs[0].uid] = y
+
     def op_sigmoid(self, node):
         a = self.materialize(node.inputs[0])
         y = self.out_value_for(node.outputs[0])
@@ -420,12 +427,22 @@ class Planner:
 
     # ---- decoder (R5) ------------------------------------------------------------------------------------
     def _sam(self, h_t, alpha, softmax_node):
-        """One soft-argmax kernel covering every decoder read-out of the maps `h_t`."""
+        """One soft-argmax kernel covering every decoder read-out of the maps `h_t`.  Several channel
+        soft-max nodes on the same maps with the same temperature (sSAM's own + the td_ChannelSoftmax of
+        action.py:202) are one computation."""
         h = self.materialize(h_t)
         outs, attrs = {}, dict(alpha=float(alpha), conf_scale=1.0)
+        twins = []
         if softmax_node is not None:
-            p_t = softmax_node.outputs[0]
-            need_prob = bool(self.out_uids.get(p_t.uid, 0))
+            twins = [n for n, _ in self.consumers.get(h_t.uid, [])
+                     if n.op == 'softmax2d' and n.attrs['alpha'] == alpha and n.uid not in self.absorbed and
+                     n.uid not in self.processed]
+            if softmax_node not in twins:
+                twins.append(softmax_node)
+        prob_users = []
+        for sm in twins:
+            p_t = sm.outputs[0]
+            need = bool(self.out_uids.get(p_t.uid, 0))
             for n, _ in self.consumers.get(p_t.uid, []):
                 if n.op == 'expect2d' and 'xy' not in outs:
                     outs['xy'] = self.out_value_for(n.outputs[0])
@@ -436,15 +453,21 @@ class Planner:
                     self.val[n.outputs[0].uid] = outs['conf_prob']
                     self.absorbed.add(n.uid)
                 else:
-                    need_prob = True
-            if need_prob:
-                outs['prob'] = self.out_value_for(p_t)
-                self.val[p_t.uid] = outs['prob']
+                    need = True
+            if need:
+                prob_users.append(p_t)
             else:
                 self.val[p_t.uid] = None  # never read
+            if sm is not softmax_node:
+                self.absorbed.add(sm.uid)
+        if prob_users:
+            outs['prob'] = self.out_value_for(prob_users[0]) if len(prob_users) == 1 else \
+                self.new_value(prob_users[0].shape)
+            for p_t in prob_users:
+                self.val[p_t.uid] = outs['prob']
         # siblings reading the raw maps
         for n, _ in self.consumers.get(h_t.uid, []):
-            if n.uid in self.absorbed or n.uid in self.processed or n is softmax_node:
+            if n.uid in self.absorbed or n.uid in self.processed or n in twins:
                 continue
             if n.op == 'jointprob' and 'conf_raw' not in outs:
                 outs['conf_raw'] = self.out_value_for(n.outputs[0])

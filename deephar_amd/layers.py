@@ -45,6 +45,11 @@ def relu(x, leakyrelu=False, name=None):
     return G.emit('relu', [x], [x.shape], name=name)[0]
 
 
+def scale(x, k, name=None):
+    """Lambda(lambda x: k * x) (action.py:291)."""
+    return G.emit('scale', [x], [x.shape], dict(k=float(k)), name=name)[0]
+
+
 def sigmoid(x, name=None):
     return G.emit('sigmoid', [x], [x.shape], name=name)[0]
 

@@ -144,3 +144,44 @@ def test_predict_accepts_float64_and_partial_batches(hip_lib, cuda):
     assert a.dtype == np.float32 and a.shape == (5, 16, 3) and np.array_equal(a, b)
     with pytest.raises(ValueError):
         m.predict(np.zeros((2, 128, 128, 3), np.float32))
+
+
+def _merge(pose_dim, T, joints, blocks, **kw):
+    from deephar_amd import graph, weights
+    from deephar_amd.models import reception, action
+    graph.reset_naming()
+    if pose_dim == 2:
+        pe = reception.build((256, 256, 3), joints, dim=2, num_blocks=blocks, num_context_per_joint=2, ksize=(5, 5))
+    else:
+        pe = reception.build((256, 256, 3), joints, dim=3, num_blocks=blocks, depth_maps=kw.get('depth_maps', 8),
+                             ksize=(5, 5))
+    m = action.build_merge_model(pe, kw.pop('num_actions', 15), (256, 256, 3), T, joints, blocks, pose_dim=pose_dim,
+                                 output_poses=True, **kw)
+    weights.init_synthetic(m, seed=0)
+    return m, weights.as_dict(m)
+
+
+@pytest.mark.parametrize('pose_dim,joints,version', [(2, 16, 'v1'), (3, 20, 'v2')])
+def test_merge_action_model_parity(pose_dim, joints, version, hip_lib, cuda):
+    """cfg 4 model family (action.build_merge_model): poses within 1e-3 px, action soft-max scores close and
+    identical arg-max labels on every one of the 9 heads (p1..p4, v1..v4, m)."""
+    from oracle import action as oact
+    T, blocks, nact = 8, 2, 15
+    kw = dict(pose_net_version=version, num_actions=nact)
+    if pose_dim == 3:
+        kw['depth_maps'] = 8
+    m, wd = _merge(pose_dim, T, joints, blocks, **dict(kw))
+    x = np.random.default_rng(7).uniform(-1, 1, (2, T, 256, 256, 3)).astype(np.float32)
+    hip = m.predict(x, batch_size=2)
+    okw = dict(pose_dim=pose_dim, pose_net_version=version, output_poses=True)
+    if pose_dim == 3:
+        okw.update(depth_maps=8, num_context_per_joint=0)
+    o32 = oact.forward_merge(wd, x, nact, joints, blocks, dtype=torch.float32, **okw)
+    o64 = oact.forward_merge(wd, x, nact, joints, blocks, dtype=torch.float64, **okw)
+    assert [h.shape for h in hip] == [o.shape for o in o64] and len(hip) == 11
+    _check('pose', hip[0], o32[0], o64[0], PX_TOL)
+    _check('conf', hip[1], o32[1], o64[1], 1e-5, rel=True)
+    for k in range(2, 11):
+        _check('action%d' % (k - 1), hip[k], o32[k], o64[k], 1e-5)
+        assert np.array_equal(hip[k].argmax(-1), o64[k].argmax(-1)), 'action label differs on head %d' % (k - 1)
+        np.testing.assert_allclose(hip[k].sum(-1), 1.0, rtol=1e-5)
