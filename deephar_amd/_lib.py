@@ -65,7 +65,8 @@ SIGNATURES = {
     'dh_kronecker_f32': (C.c_int, [vp, C.c_int, vp, C.c_int, vp, C.c_int] + [C.c_int] * 4 + [vp]),
     'dh_global_maxmin_softmax_f32': (C.c_int, [vp, C.c_int, vp] + [C.c_int] * 4 + [vp]),
     'dh_copy_channels_f32': (C.c_int, [vp, C.c_int, vp, C.c_int, i64, C.c_int, vp]),
-    'dh_zeropad2d_f32': (C.c_int, [vp, vp] + [C.c_int] * 6 + [vp]),
+    'dh_zeropad2d_f32': (C.c_int, [vp, vp] + [C.c_int] * 8 + [vp]),
+    'dh_depth_from_maps_f32': (C.c_int, [vp, C.c_int, vp, C.c_int, vp, C.c_int] + [C.c_int] * 3 + [vp]),
     'dh_graph_begin_capture': (C.c_int, [vp]),
     'dh_graph_end_capture': (C.c_int, [vp, C.POINTER(vp)]),
     'dh_graph_launch': (C.c_int, [vp, vp]),

@@ -131,9 +131,16 @@ int dh_copy_channels_f32(const float* x, int ldx, float* y, int ldy, int64_t npi
   return launch_copy_channels(x, ldx, y, ldy, (long long)npix, C, S(stream));
 }
 
-int dh_zeropad2d_f32(const float* x, float* y, int B, int H, int W, int C, int OH, int OW, void* stream) {
+int dh_zeropad2d_f32(const float* x, float* y, int B, int H, int W, int C, int OH, int OW, int PT, int PL,
+                     void* stream) {
   if (x == nullptr || y == nullptr) return DH_EINVAL;
-  return launch_zeropad(x, y, B, H, W, C, OH, OW, S(stream));
+  return launch_zeropad(x, y, B, H, W, C, OH, OW, PT, PL, S(stream));
+}
+
+int dh_depth_from_maps_f32(const float* d, int ldd, const float* h, int ldh, float* z, int ldz, int F, int HW,
+                           int J, void* stream) {
+  if (d == nullptr || h == nullptr || z == nullptr) return DH_EINVAL;
+  return launch_depth_from_maps(d, ldd, h, ldh, z, ldz, F, HW, J, S(stream));
 }
 
 // ---- graphs / events ---------------------------------------------------------------------------

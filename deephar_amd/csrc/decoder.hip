@@ -196,6 +196,37 @@ __global__ __launch_bounds__(256) void softargmax1d_kernel(const float* __restri
   if (vz != nullptr) vz[idx] = m;
 }
 
+// z[f, j] = sum_p sigmoid(d[f,p,j]) * h[f,p,j]   (spnet.py:201-205: depth as the probability-weighted mean of
+// the sigmoid depth maps).  Workgroup = (frame, 16 channels) like the soft-argmax kernel.
+__global__ __launch_bounds__(NTH) void depth_from_maps_kernel(const float* __restrict__ d, int ldd,
+                                                              const float* __restrict__ h, int ldh,
+                                                              float* __restrict__ z, int ldz, int HW, int J) {
+  __shared__ float red[NW][CG];
+  const int tid = threadIdx.x;
+  const int cc = tid % CG, pl = tid / CG;
+  const int groups = (J + CG - 1) / CG;
+  const int f = blockIdx.x / groups;
+  const int c = (blockIdx.x % groups) * CG + cc;
+  float acc = 0.f;
+  if (c < J) {
+    const float* dp = d + (size_t)f * HW * ldd + c;
+    const float* hp = h + (size_t)f * HW * ldh + c;
+    for (int px = pl; px < HW; px += PL) {
+      const float sg = 1.f / (1.f + expf(-dp[(size_t)px * ldd]));
+      acc = fmaf(sg, hp[(size_t)px * ldh], acc);
+    }
+  }
+  acc = wave_sum_cg(acc);
+  if ((tid & 63) < CG) red[tid >> 6][cc] = acc;
+  __syncthreads();
+  if (tid < CG && c < J) {
+    float t = red[0][cc];
+#pragma unroll
+    for (int w = 1; w < NW; ++w) t += red[w][cc];
+    z[((size_t)f * J + c) * ldz] = t;
+  }
+}
+
 // f[b, j, c] = sum_p hm[b,p,j] * x[b,p,c].  Workgroup = (b, 64-channel slab); each thread owns one channel
 // and JT joints at a time; the heat-map tile for a chunk of pixels is staged in LDS and broadcast.
 constexpr int KR_PCH = 64;   // pixels per LDS chunk
@@ -311,6 +342,14 @@ int launch_softargmax1d(const float* hz, const float* grid, float* z, int ldz, f
   if (F <= 0 || D <= 0 || J <= 0) return DH_EINVAL;
   hipLaunchKernelGGL(softargmax1d_kernel, dim3((F * J + 255) / 256), dim3(256), 0, s, hz, grid, z, ldz, vz, F, D,
                      J);
+  return check_launch();
+}
+
+int launch_depth_from_maps(const float* d, int ldd, const float* h, int ldh, float* z, int ldz, int F, int HW,
+                           int J, hipStream_t s) {
+  if (F <= 0 || HW <= 0 || J <= 0) return DH_EINVAL;
+  hipLaunchKernelGGL(depth_from_maps_kernel, dim3((unsigned)(F * ((J + CG - 1) / CG))), dim3(NTH), 0, s, d, ldd, h,
+                     ldh, z, ldz, HW, J);
   return check_launch();
 }
 

@@ -33,7 +33,10 @@ int launch_kronecker(const float* hm, int ldh, const float* x, int ldx, float* f
 int launch_global_maxmin_softmax(const float* x, int ldx, float* y, int B, int P, int C, int softmax,
                                  hipStream_t s);
 int launch_copy_channels(const float* x, int ldx, float* y, int ldy, long long npix, int C, hipStream_t s);
-int launch_zeropad(const float* x, float* y, int B, int H, int W, int C, int OH, int OW, hipStream_t s);
+int launch_zeropad(const float* x, float* y, int B, int H, int W, int C, int OH, int OW, int PT, int PL,
+                   hipStream_t s);
+int launch_depth_from_maps(const float* d, int ldd, const float* h, int ldh, float* z, int ldz, int F, int HW,
+                           int J, hipStream_t s);
 
 inline int check_launch() {
   hipError_t e = hipGetLastError();

@@ -221,7 +221,8 @@ __global__ __launch_bounds__(256) void copy_channels_kernel(const float* __restr
 }
 
 __global__ __launch_bounds__(256) void zeropad_kernel(const float* __restrict__ x, float* __restrict__ y,
-                                                      int B, int H, int W, int C, int OH, int OW) {
+                                                      int B, int H, int W, int C, int OH, int OW, int PT,
+                                                      int PL) {
   const long long total = (long long)B * OH * OW * C;
   for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
        idx += (long long)gridDim.x * blockDim.x) {
@@ -230,7 +231,9 @@ __global__ __launch_bounds__(256) void zeropad_kernel(const float* __restrict__ 
     const int w = (int)(t % OW); t /= OW;
     const int h = (int)(t % OH);
     const int b = (int)(t / OH);
-    y[idx] = (h < H && w < W) ? x[((size_t)(b * H + h) * W + w) * C + c] : 0.f;
+    const int ih = h - PT, iw = w - PL;
+    y[idx] = ((unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W)
+                 ? x[((size_t)(b * H + ih) * W + iw) * C + c] : 0.f;
   }
 }
 
@@ -307,10 +310,11 @@ int launch_copy_channels(const float* x, int ldx, float* y, int ldy, long long n
   return check_launch();
 }
 
-int launch_zeropad(const float* x, float* y, int B, int H, int W, int C, int OH, int OW, hipStream_t s) {
-  if (B <= 0 || C <= 0 || OH < H || OW < W) return DH_EINVAL;
+int launch_zeropad(const float* x, float* y, int B, int H, int W, int C, int OH, int OW, int PT, int PL,
+                   hipStream_t s) {
+  if (B <= 0 || C <= 0 || PT < 0 || PL < 0 || OH < H + PT || OW < W + PL) return DH_EINVAL;
   hipLaunchKernelGGL(zeropad_kernel, dim3(grid_for((long long)B * OH * OW * C)), dim3(256), 0, s, x, y, B, H, W, C,
-                     OH, OW);
+                     OH, OW, PT, PL);
   return check_launch();
 }
 

@@ -275,7 +275,11 @@ class BoundPlan:
             x, y = s.ins['x'], s.outs['y']
             self.calls.append((lib.dh_zeropad2d_f32,
                                (P(x), P(y), n * x.lead(3), x.shape[-3], x.shape[-2], x.C, y.shape[-3],
-                                y.shape[-2]), s))
+                                y.shape[-2], a.get('pt', 0), a.get('pl', 0)), s))
+        elif k == 'depthsum':
+            d, h, z = s.ins['d'], s.ins['h'], s.outs['z']
+            self.calls.append((lib.dh_depth_from_maps_f32,
+                               (P(d), d.ld, P(h), h.ld, P(z), z.ld, n * d.lead(3), d.shape[-3] * d.shape[-2], d.C), s))
         else:
             raise NotImplementedError('no binding for step kind %r' % k)
 

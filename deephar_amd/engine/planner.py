@@ -422,8 +422,16 @@ class Planner:
             self.emit('copy', dict(x=x), dict(y=d), name='densify')
             x = d
         y = self.new_value(node.outputs[0].shape)
-        self.emit('zeropad', dict(x=x), dict(y=y), name=node.name or 'zeropad')
+        self.emit('zeropad', dict(x=x), dict(y=y), dict(pt=node.attrs.get('pt', 0), pl=node.attrs.get('pl', 0)),
+                  name=node.name or 'zeropad')
         self.val[node.outputs[0].uid] = y
+
+    def op_depthsum(self, node):
+        d = self.materialize(node.inputs[0])
+        h = self.materialize(node.inputs[1])
+        z = self.out_value_for(node.outputs[0])
+        self.emit('depthsum', dict(d=d, h=h), dict(z=z), name=node.name or 'depthsum')
+        self.val[node.outputs[0].uid] = z
 
     # ---- decoder (R5) ------------------------------------------------------------------------------------
     def _sam(self, h_t, alpha, softmax_node):
@@ -444,12 +452,14 @@ class Planner:
             p_t = sm.outputs[0]
             need = bool(self.out_uids.get(p_t.uid, 0))
             for n, _ in self.consumers.get(p_t.uid, []):
-                if n.op == 'expect2d' and 'xy' not in outs:
-                    outs['xy'] = self.out_value_for(n.outputs[0])
-                    self.val[n.outputs[0].uid] = outs['xy']
+                if n.op == 'expect2d':
+                    if 'xy' not in outs:
+                        outs['xy'] = self.out_value_for(n.outputs[0])
+                    self.val[n.outputs[0].uid] = outs['xy']      # twins alias the first read-out
                     self.absorbed.add(n.uid)
-                elif n.op == 'jointprob' and 'conf_prob' not in outs and n.attrs.get('scale', 1.0) == 1.0:
-                    outs['conf_prob'] = self.out_value_for(n.outputs[0])
+                elif n.op == 'jointprob' and n.attrs.get('scale', 1.0) == 1.0:
+                    if 'conf_prob' not in outs:
+                        outs['conf_prob'] = self.out_value_for(n.outputs[0])
                     self.val[n.outputs[0].uid] = outs['conf_prob']
                     self.absorbed.add(n.uid)
                 else:

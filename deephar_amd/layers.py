@@ -148,12 +148,18 @@ def upsampling2d(x, kernel_size=(2, 2), name=None):
 
 
 def ZeroPadding2D(x, padding, name=None):
-    """keras ZeroPadding2D(((top,bottom),(left,right))); the hot path only pads bottom/right."""
+    """keras ZeroPadding2D(((top, bottom), (left, right))) (spnet.py:124-133)."""
     (pt, pb), (pl, pr) = padding
-    if pt or pl:
-        raise NotImplementedError('only bottom/right zero padding is used (spnet.py:98-107)')
-    return G.emit('zeropad', [x], [x.shape[:-3] + (x.shape[-3] + pb, x.shape[-2] + pr, x.shape[-1])],
-                  dict(pb=pb, pr=pr), name=name)[0]
+    shape = x.shape[:-3] + (x.shape[-3] + pt + pb, x.shape[-2] + pl + pr, x.shape[-1])
+    return G.emit('zeropad', [x], [shape], dict(pt=int(pt), pl=int(pl)), name=name)[0]
+
+
+def depth_from_maps(d, h, name=None):
+    """spnet.py:201-205: Activation('sigmoid')(d) -> multiply([d, h]) -> K.sum over (H, W) -> expand_dims:
+    [.., H, W, J] x [.., H, W, J] -> [.., J, 1]."""
+    if d.shape != h.shape:
+        raise ValueError('depth_from_maps: %s vs %s' % (d.shape, h.shape))
+    return G.emit('depthsum', [d, h], [d.shape[:-3] + (d.shape[-1], 1)], name=name)[0]
 
 
 # ---- soft-argmax / confidence ------------------------------------------------------------------------

@@ -174,7 +174,14 @@ int dh_global_maxmin_softmax_f32(const float* x, int ldx, float* y, int B, int P
 
 /* keras concatenate / Lambda channel slicing fallback, ZeroPadding2D (spnet.py:98-107) */
 int dh_copy_channels_f32(const float* x, int ldx, float* y, int ldy, int64_t npix, int C, void* stream);
-int dh_zeropad2d_f32(const float* x, float* y, int B, int H, int W, int C, int OH, int OW, void* stream);
+/* y is [B,OH,OW,C]; x [B,H,W,C] lands at row offset PT, column offset PL, zeros elsewhere */
+int dh_zeropad2d_f32(const float* x, float* y, int B, int H, int W, int C, int OH, int OW, int PT, int PL,
+                     void* stream);
+
+/* SPNet depth read-out (spnet.py:201-205): z[f,j] = sum_hw sigmoid(d[f,h,w,j]) * prob[f,h,w,j]
+ * (Activation('sigmoid') -> multiply -> Lambda K.sum over (H,W)) */
+int dh_depth_from_maps_f32(const float* d, int ldd, const float* h, int ldh, float* z, int ldz, int F, int HW,
+                           int J, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------
  * Stream-ordered runtime helpers (no torch types): graphs for launch-bound replay, events for timing.

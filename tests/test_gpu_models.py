@@ -185,3 +185,54 @@ def test_merge_action_model_parity(pose_dim, joints, version, hip_lib, cuda):
         _check('action%d' % (k - 1), hip[k], o32[k], o64[k], 1e-5)
         assert np.array_equal(hip[k].argmax(-1), o64[k].argmax(-1)), 'action label differs on head %d' % (k - 1)
         np.testing.assert_allclose(hip[k].sum(-1), 1.0, rtol=1e-5)
+
+
+def _spnet(T, layout, num_actions, pyramids, action_pyramids, feats):
+    from deephar_amd import graph, weights, utils
+    from deephar_amd.config import ModelConfig
+    from deephar_amd.models import spnet
+    graph.reset_naming()
+    lay = getattr(utils, layout)
+    cfg = ModelConfig((T, 256, 256, 3), lay, num_actions=[num_actions], num_pyramids=pyramids,
+                      action_pyramids=action_pyramids, num_levels=4, pose_replica=False, num_pose_features=feats,
+                      num_visual_features=feats)
+    m = spnet.build(cfg)
+    weights.init_synthetic(m, seed=0)
+    ocfg = dict(num_joints=lay.num_joints, dim=lay.dim, num_actions=[num_actions], num_pyramids=pyramids,
+                action_pyramids=action_pyramids, num_levels=4, kernel_size=(5, 5), growth=96, image_div=8,
+                num_pose_features=feats, num_visual_features=feats, sam_alpha=1)
+    return m, cfg, weights.as_dict(m), ocfg
+
+
+@pytest.mark.parametrize('T,layout,nact,pyr,apyr,feats', [
+    (8, 'pa17j3d', 60, 2, [1, 2], 192),     # exp/ntu/eval_ntu_multitask.py:35-38 (cfg 5 family), time_stride 1
+    (16, 'pa16j2d', 15, 2, [2], 160),       # Penn-like 2-D, T>=16 -> time_stride 2, action only on pyramid 2
+])
+def test_spnet_multitask_parity(T, layout, nact, pyr, apyr, feats, hip_lib, cuda):
+    """SPNet pose + action outputs vs the oracle; split_model() slices the same numbers."""
+    from deephar_amd.models import spnet, split_model
+    from oracle import spnet as osp
+    m, cfg, wd, ocfg = _spnet(T, layout, nact, pyr, apyr, feats)
+    x = np.random.default_rng(11).uniform(-1, 1, (1, T, 256, 256, 3)).astype(np.float32)
+    hip = m.predict(x, batch_size=1)
+    o32 = osp.forward(wd, x, ocfg, dtype=torch.float32)
+    o64 = osp.forward(wd, x, ocfg, dtype=torch.float64)
+    npose = spnet.get_num_predictions(pyr, 4)
+    nact_out = spnet.get_num_predictions(len(apyr), 4)
+    assert len(hip) == npose + nact_out and [h.shape for h in hip] == [o.shape for o in o64]
+    dim = ocfg['dim']
+    for k in range(npose):
+        _check('pose%d.xy' % k, hip[k][..., :2], o32[k][..., :2], o64[k][..., :2], PX_TOL)
+        if dim == 3:
+            _check('pose%d.z' % k, hip[k][..., 2], o32[k][..., 2], o64[k][..., 2], PX_TOL)
+        _check('pose%d.c' % k, hip[k][..., dim], o32[k][..., dim], o64[k][..., dim], 2e-6)
+    for k in range(npose, npose + nact_out):
+        _check('action%d' % (k - npose), hip[k], o32[k], o64[k], 1e-5)
+        assert np.array_equal(hip[k].argmax(-1), o64[k].argmax(-1))
+    pose_model, act_model = split_model(m, cfg)
+    a = act_model.predict(x, batch_size=1)
+    a = a if isinstance(a, list) else [a]
+    for k in range(nact_out):
+        assert np.array_equal(a[k], hip[npose + k])
+    last = pose_model.predict(x, batch_size=1)[-1]
+    assert np.array_equal(last, hip[npose - 1])
