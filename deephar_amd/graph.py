@@ -161,11 +161,13 @@ def Input(shape, name=None):
     return Tensor(tuple(shape), None, 0, name or 'input')
 
 
-def topo_nodes(outputs):
+def topo_nodes(outputs, stop=None):
     """All nodes reachable from `outputs`, in a deterministic topological order (DFS post-order following
-    input order, i.e. the order the builder would have executed them)."""
+    input order, i.e. the order the builder would have executed them).  Tensors whose uid is in `stop` are
+    treated as sources: their producers are not visited."""
+    stop = stop or set()
     order, seen = [], set()
-    stack = [(t.node, False) for t in reversed(outputs) if t.node is not None]
+    stack = [(t.node, False) for t in reversed(outputs) if t.node is not None and t.uid not in stop]
     while stack:
         node, done = stack.pop()
         if done:
@@ -176,35 +178,43 @@ def topo_nodes(outputs):
         seen.add(node.uid)
         stack.append((node, True))
         for t in reversed(node.inputs):
-            if t.node is not None and t.node.uid not in seen:
+            if t.node is not None and t.node.uid not in seen and t.uid not in stop:
                 stack.append((t.node, False))
     return order
 
 
-def clone_subgraph(inputs, outputs, new_inputs):
+def clone_subgraph(inputs, outputs, new_inputs, relead=None, allow_unused=False):
     """Re-instantiate the sub-graph inputs->outputs on `new_inputs` (a nested Model being called on a new
     tensor, e.g. reception.py:93,131 or TimeDistributed(model) in action.py:124-125).  Layers (weights) are
-    shared; leading dims of the new inputs (clip length T) are propagated to every cloned tensor."""
+    shared; leading dims of the new inputs (clip length T) are propagated to every cloned tensor.
+    `inputs` may be internal tensors (a cut through the graph).  relead=(T, T') rewrites a leading frame axis
+    of length T to T' on every cloned tensor (valid for frame-independent sub-graphs, deephar_amd/parallel.py)."""
     if len(inputs) != len(new_inputs):
         raise ValueError('model expects %d inputs, got %d' % (len(inputs), len(new_inputs)))
     mapping = {}
     lead = None
+
+    def fix(shape):
+        if relead is not None and len(shape) > 0 and shape[0] == relead[0]:
+            return (relead[1],) + tuple(shape[1:])
+        return tuple(shape)
+
     for old, new in zip(inputs, new_inputs):
         k = len(new.shape) - len(old.shape)
-        if k < 0 or tuple(new.shape[k:]) != tuple(old.shape):
+        if k < 0 or tuple(new.shape[k:]) != fix(old.shape):
             raise ValueError('input shape mismatch: model expects %s, got %s' % (old.shape, new.shape))
         if lead is None:
             lead = tuple(new.shape[:k])
         elif lead != tuple(new.shape[:k]):
             raise ValueError('inconsistent leading dims across inputs')
         mapping[old.uid] = new
-    for node in topo_nodes(outputs):
+    for node in topo_nodes(outputs, stop={t.uid for t in inputs}):
         ins = []
         for t in node.inputs:
             if t.uid not in mapping:
                 raise ValueError('graph is disconnected: %r is not reachable from the model inputs' % t)
             ins.append(mapping[t.uid])
-        new = Node(node.op, ins, [lead + o.shape for o in node.outputs], node.attrs, node.layers, node.name)
+        new = Node(node.op, ins, [lead + fix(o.shape) for o in node.outputs], node.attrs, node.layers, node.name)
         for o, n in zip(node.outputs, new.outputs):
             mapping[o.uid] = n
     res = []

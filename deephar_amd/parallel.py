@@ -1,0 +1,186 @@
+"""Multi-GPU execution: one process per GPU, torch.distributed (backend "nccl" = RCCL over xGMI on ROCm).
+
+The reference is single-GPU (run.sh:29); what shards here is the structure of the hot path itself
+(SURVEY.md 8e):
+  * frames / clips are independent  -> `shard_slice` + `predict_sharded`: pure data parallelism, no collective
+    on the data path (used by bench.py and the pose-only evaluations);
+  * inside one clip every layer before the action head is frame independent (TimeDistributed,
+    layers.py:63-104; inference BatchNorm) -> `split_frames` cuts a clip model into a FRAME stage (runs on
+    T/G frames per rank) and a HEAD stage (needs all T frames), and `ShardedClipModel` joins them with ONE
+    all-gather of a packed [N, T/G, J, C_packed] fp32 buffer per clip batch.  Payloads are <= ~1 MB per clip,
+    so the exchange is latency bound; ring vs direct does not matter at this size.
+"""
+import numpy as np
+
+from . import graph as G
+from . import layers as L
+from .model import Model
+
+# number of trailing dims an op actually couples; everything in front of them is batch for that op
+_CORE_RANK = {
+    'conv': 3, 'sepconv': 3, 'pool': 3, 'upsample': 3, 'zeropad': 3, 'softmax2d': 3, 'expect2d': 3,
+    'jointprob': 3, 'kronecker': 3, 'depthmean': 3, 'depthsum': 3, 'globalmax2d': 3, 'globalmaxmin': 3,
+    'context_agg': 2, 'softargmax1d': 2, 'globalmax1d': 2,
+    'relu': 1, 'bn': 1, 'add': 1, 'mul': 1, 'sigmoid': 1, 'scale': 1, 'concat': 1, 'slice': 1, 'softmax': 1,
+}
+
+
+def shard_slice(n, rank, world):
+    """Contiguous [lo, hi) share of n items for `rank` (the first n % world ranks get one extra)."""
+    q, r = divmod(n, world)
+    lo = rank * q + min(rank, r)
+    return lo, lo + q + (1 if rank < r else 0)
+
+
+def predict_sharded(model, x, rank, world, batch_size=32):
+    """Data-parallel predict: this rank runs its contiguous share of the batch, nothing is exchanged."""
+    lo, hi = shard_slice(len(x), rank, world)
+    return model.predict(x[lo:hi], batch_size=batch_size), (lo, hi)
+
+
+# ---------------------------------------------------------------------------------------------------------
+# graph partition
+# ---------------------------------------------------------------------------------------------------------
+
+def frame_level_nodes(model):
+    """uids of nodes that treat the clip's frame axis (leading dim of the single model input) purely as batch."""
+    t_in = model.inputs[0]
+    frame_t = {t_in.uid}
+    frame_n = set()
+    for n in model._nodes:
+        core = _CORE_RANK.get(n.op)
+        if n.op == 'reshape':
+            ok = len(n.inputs[0].shape) >= 2 and len(n.outputs[0].shape) >= 2 and \
+                n.inputs[0].shape[0] == n.outputs[0].shape[0]
+        else:
+            ok = core is not None and all(len(t.shape) > core for t in n.inputs)
+        if ok and all(t.uid in frame_t for t in n.inputs):
+            frame_n.add(n.uid)
+            for o in n.outputs:
+                frame_t.add(o.uid)
+    return frame_n, frame_t
+
+
+def split_frames(model, shards):
+    """Cut a clip model (single input [T, H, W, C]) into (frame_model, head_model, info).
+
+    frame_model : input [T/shards, H, W, C] -> ONE packed output [T/shards, J, C_packed] holding, side by side
+                  on the channel axis, every tensor the head stage or the caller needs from the frame stage
+    head_model  : inputs = those tensors at full T (or None when the model has no temporal part)
+    info        : dict(cut=[(shape_without_T, channel_offset, channels)], passthrough={output index: cut index},
+                       head_outputs=[output indices produced by the head])
+    """
+    if len(model.inputs) != 1:
+        raise ValueError('split_frames expects a single-input clip model')
+    T = model.inputs[0].shape[0]
+    if T % shards:
+        raise ValueError('clip length %d does not divide into %d shards' % (T, shards))
+    frame_n, frame_t = frame_level_nodes(model)
+    consumers = {}
+    for n in model._nodes:
+        for t in n.inputs:
+            consumers.setdefault(t.uid, []).append(n)
+    cut, seen = [], set()
+    for n in model._nodes:                        # deterministic order: graph order
+        if n.uid not in frame_n:
+            continue
+        for o in n.outputs:
+            used_by_head = any(c.uid not in frame_n for c in consumers.get(o.uid, []))
+            is_out = any(o.uid == t.uid for t in model.outputs)
+            if (used_by_head or is_out) and o.uid not in seen:
+                seen.add(o.uid)
+                cut.append(o)
+    if not cut:
+        raise ValueError('model has no frame-level stage')
+    lead = cut[0].shape[:-1]
+    if any(t.shape[:-1] != lead for t in cut):
+        raise NotImplementedError('cut tensors with different pixel shapes: %s' % [t.shape for t in cut])
+
+    # frame stage, re-built on T/shards frames (shapes: replace the leading T)
+    Tl = T // shards
+    x_local = L.Input((Tl,) + model.inputs[0].shape[1:])
+    local = G.clone_subgraph(model.inputs, cut, [x_local], relead=(T, Tl))
+    packed = L.concatenate(local) if len(local) > 1 else local[0]
+    frame_model = Model(x_local, packed, name=(model.name or 'model') + '_frames')
+
+    offs, off = [], 0
+    for t in cut:
+        offs.append((t.shape[1:], off, t.shape[-1]))
+        off += t.shape[-1]
+    passthrough, head_outputs = {}, []
+    cut_index = {t.uid: i for i, t in enumerate(cut)}
+    for k, t in enumerate(model.outputs):
+        if t.uid in cut_index:
+            passthrough[k] = cut_index[t.uid]
+        else:
+            head_outputs.append(k)
+    head_model = None
+    if head_outputs:
+        new_in = [L.Input(t.shape) for t in cut]
+        outs = G.clone_subgraph(cut, [model.outputs[k] for k in head_outputs], new_in, allow_unused=True)
+        head_model = Model(new_in, outs, name=(model.name or 'model') + '_head')
+    info = dict(cut=offs, passthrough=passthrough, head_outputs=head_outputs, packed_channels=off, T=T, Tl=Tl)
+    return frame_model, head_model, info
+
+
+# ---------------------------------------------------------------------------------------------------------
+# runtime
+# ---------------------------------------------------------------------------------------------------------
+
+def all_gather_frames(local, group=None):
+    """All-gather a [N, T_local, ...] tensor along the frame axis -> [N, T, ...].  Works on CUDA tensors
+    (RCCL) and CPU tensors (gloo).  One collective per call."""
+    import torch
+    import torch.distributed as dist
+    world = dist.get_world_size(group)
+    if world == 1:
+        return local
+    local = local.contiguous()
+    parts = [torch.empty_like(local) for _ in range(world)]
+    dist.all_gather(parts, local, group=group)
+    return torch.cat(parts, dim=1)
+
+
+class ShardedClipModel:
+    """Frame-sharded execution of a clip model over the ranks of a process group.
+
+    frame_fn(x_local [N, T/G, H, W, C]) -> packed [N, T/G, J, Cp] (torch tensor, any device)
+    head_fn(list of [N, T, J, c_i])     -> list of arrays / tensors
+    The defaults run the two stages on the HIP engine; tests inject CPU stand-ins to exercise the collective
+    and the bookkeeping with the gloo backend."""
+
+    def __init__(self, model, rank=None, world=None, group=None, frame_fn=None, head_fn=None):
+        import torch.distributed as dist
+        self.group = group
+        self.rank = dist.get_rank(group) if rank is None else rank
+        self.world = dist.get_world_size(group) if world is None else world
+        self.model = model
+        self.frame_model, self.head_model, self.info = split_frames(model, self.world)
+        self.frame_fn = frame_fn or self._frame_hip
+        self.head_fn = head_fn or self._head_hip
+
+    # -- default stages on the GPU -----------------------------------------------------------------------
+    def _frame_hip(self, x_local):
+        import torch
+        out = self.frame_model.predict(x_local, batch_size=len(x_local))
+        return torch.from_numpy(out).to(self.frame_model.executor.device)
+
+    def _head_hip(self, tensors):
+        outs = self.head_model.predict([t.cpu().numpy() for t in tensors], batch_size=len(tensors[0]))
+        return outs if isinstance(outs, list) else [outs]
+
+    def predict(self, clips):
+        """clips: [N, T, H, W, C] (the same array on every rank).  Returns the model's outputs (host arrays)."""
+        info = self.info
+        lo = self.rank * info['Tl']
+        packed = self.frame_fn(np.ascontiguousarray(clips[:, lo:lo + info['Tl']]))
+        full = all_gather_frames(packed, self.group)                       # [N, T, J, Cp]
+        parts = [full[..., off:off + c] for (_, off, c) in info['cut']]
+        outs = [None] * len(self.model.outputs)
+        for k, ci in info['passthrough'].items():
+            outs[k] = parts[ci].contiguous().cpu().numpy()
+        if self.head_model is not None:
+            head = self.head_fn([p.contiguous() for p in parts])
+            for k, o in zip(info['head_outputs'], head):
+                outs[k] = o if isinstance(o, np.ndarray) else o.cpu().numpy()
+        return outs

@@ -98,6 +98,57 @@ def heatmap_weighting(W, x):
     return ops.sepconv2d(x, dw, pw, (1, 1), 'valid')
 
 
+def merge_frames(W, frames, num_joints, num_blocks, pose_dim=2, depth_maps=8, num_context_per_joint=2,
+                 ksize=(5, 5)):
+    """Frame-independent stage of the merge model (action.py:112-205 / 208-297 + the kronecker pooling of :359):
+    frames [F, H, W, 3] -> y [F, J, dim], p [F, J, 1], pooled appearance features f [F, J, C]."""
+    x1 = R.stem(W, frames)
+    xb1 = R.reception_block(W, x1, 'rBlock1', ksize)
+    if pose_dim == 2:
+        num_heatmaps = (num_context_per_joint + 1) * num_joints
+        h = pose_regressor(W, xb1, num_blocks, ksize, num_heatmaps)
+        if num_context_per_joint > 0:
+            hs, hc = h[..., :num_joints], h[..., num_joints:]
+        else:
+            hs = h
+        ys = ops.softargmax2d(hs)
+        if num_context_per_joint > 0:
+            yc = ops.softargmax2d(hc)
+            pc = ops.joints_probability(hc)
+            y = ops.context_aggregation(ys, yc, pc, num_joints, num_context_per_joint, 0.8)
+        else:
+            y = ys
+        p = ops.joints_probability(4 * hs)
+        hmaps = ops.channel_softmax_2d(hs)
+    elif pose_dim == 3:
+        h = pose_regressor(W, xb1, num_blocks, ksize, depth_maps * num_joints)
+        f, rows, cols, ch = h.shape
+        assert ch == depth_maps * num_joints
+        h5 = h.reshape(f, rows, cols, depth_maps, num_joints)
+        hxy = h5.mean(dim=3)
+        hz = h5.mean(dim=(1, 2))
+        y = torch.cat([ops.softargmax2d(hxy), ops.softargmax1d(hz)], dim=-1)
+        v = torch.amax(hxy, dim=(1, 2)) + torch.amax(hz, dim=1)
+        p = torch.sigmoid(2 * v.unsqueeze(-1))
+        hmaps = ops.channel_softmax_2d(hxy)
+    else:
+        raise ValueError('pose_dim must be 2 or 3')
+    return y, p, ops.kronecker_prod(hmaps, xb1)
+
+
+def merge_head(W, y, p, feat, num_actions, pose_net_version='v1', weighted_merge=True):
+    """Clip-coupled stage (action.py:351-396): y [N,T,J,dim], p [N,T,J,1], feat [N,T,J,C] -> 9 score vectors."""
+    out_pose = pose_model(W, y, p, num_actions, pose_net_version)
+    out_vis = visual_model(W, feat, num_actions)
+    outputs = [action_top(o) for o in out_pose] + [action_top(o) for o in out_vis]
+    pm, vm = out_pose[-1], out_vis[-1]
+    if weighted_merge:
+        pm = heatmap_weighting(W, pm)
+        vm = heatmap_weighting(W, vm)
+    outputs.append(action_top(pm + vm))
+    return outputs
+
+
 def forward_merge(weights, clips, num_actions, num_joints, num_blocks, pose_dim=2, depth_maps=8,
                   num_context_per_joint=2, pose_net_version='v1', output_poses=False, weighted_merge=True,
                   ksize=(5, 5), dtype=torch.float32, taps=None):
@@ -109,67 +160,16 @@ def forward_merge(weights, clips, num_actions, num_joints, num_blocks, pose_dim=
         clips = torch.from_numpy(np.ascontiguousarray(clips)).to(dtype)
         n, t = clips.shape[:2]
         frames = clips.reshape((n * t,) + tuple(clips.shape[2:]))
-        x1 = R.stem(W, frames)
-        xb1 = R.reception_block(W, x1, 'rBlock1', ksize)
-
-        if pose_dim == 2:
-            num_heatmaps = (num_context_per_joint + 1) * num_joints
-            h = pose_regressor(W, xb1, num_blocks, ksize, num_heatmaps)
-            # action.py:186-203
-            if num_context_per_joint > 0:
-                hs, hc = h[..., :num_joints], h[..., num_joints:]
-            else:
-                hs = h
-            ys = ops.softargmax2d(hs)
-            if num_context_per_joint > 0:
-                yc = ops.softargmax2d(hc)
-                pc = ops.joints_probability(hc)
-                y = ops.context_aggregation(ys, yc, pc, num_joints, num_context_per_joint, 0.8)
-            else:
-                y = ys
-            p = ops.joints_probability(4 * hs)
-            hmaps = ops.channel_softmax_2d(hs)
-        elif pose_dim == 3:
-            h = pose_regressor(W, xb1, num_blocks, ksize, depth_maps * num_joints)
-            # action.py:268-295
-            f, rows, cols, ch = h.shape
-            assert ch == depth_maps * num_joints
-            h5 = h.reshape(f, rows, cols, depth_maps, num_joints)
-            hxy = h5.mean(dim=3)
-            hz = h5.mean(dim=(1, 2))
-            y = torch.cat([ops.softargmax2d(hxy), ops.softargmax1d(hz)], dim=-1)
-            v = torch.amax(hxy, dim=(1, 2)) + torch.amax(hz, dim=1)
-            p = torch.sigmoid(2 * v.unsqueeze(-1))
-            hmaps = ops.channel_softmax_2d(hxy)
-        else:
-            raise ValueError('pose_dim must be 2 or 3')
-
+        y, p, feat = merge_frames(W, frames, num_joints, num_blocks, pose_dim, depth_maps, num_context_per_joint,
+                                  ksize)
         J = num_joints
         y = y.reshape(n, t, J, pose_dim)
         p = p.reshape(n, t, J, 1)
-        outputs = []
-        if output_poses:
-            outputs += [y, p]
-        if taps is not None:
-            taps.update(y=y, p=p, hmaps=hmaps, xb1=xb1)
-
-        out_pose = pose_model(W, y, p, num_actions, pose_net_version)
-
-        feat = ops.kronecker_prod(hmaps, xb1)                     # [N*T, J, C]
         feat = feat.reshape(n, t, J, feat.shape[-1])
+        outputs = [y, p] if output_poses else []
         if taps is not None:
-            taps['f'] = feat
-        out_vis = visual_model(W, feat, num_actions)
-
-        for o in out_pose:
-            outputs.append(action_top(o))
-        for o in out_vis:
-            outputs.append(action_top(o))
-        pm, vm = out_pose[-1], out_vis[-1]
-        if weighted_merge:
-            pm = heatmap_weighting(W, pm)
-            vm = heatmap_weighting(W, vm)
-        outputs.append(action_top(pm + vm))
+            taps.update(y=y, p=p, f=feat)
+        outputs += merge_head(W, y, p, feat, num_actions, pose_net_version, weighted_merge)
         if taps is not None:
             for k in list(taps):
                 taps[k] = taps[k].numpy()

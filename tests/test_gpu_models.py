@@ -236,3 +236,43 @@ def test_spnet_multitask_parity(T, layout, nact, pyr, apyr, feats, hip_lib, cuda
         assert np.array_equal(a[k], hip[npose + k])
     last = pose_model.predict(x, batch_size=1)[-1]
     assert np.array_equal(last, hip[npose - 1])
+
+
+def test_frame_sharded_stages_match_full_model(hip_lib, cuda):
+    """cfg 4 (frame-shard + all-gather): running the FRAME stage on T/2 frames per 'rank' and the HEAD stage on
+    the gathered [T, J, C] tensors reproduces the un-sharded clip model bit for bit (frames are independent and
+    every kernel is batch-size invariant), for the merge model and for SPNet."""
+    from deephar_amd import parallel
+    for builder in ('merge', 'spnet'):
+        if builder == 'merge':
+            m, _ = _merge(2, 8, 16, 2, num_actions=15)
+        else:
+            m, _, _, _ = _spnet(8, 'pa17j3d', 60, 2, [1, 2], 192)
+        clips = np.random.default_rng(21).uniform(-1, 1, (2, 8, 256, 256, 3)).astype(np.float32)
+        full = m.predict(clips, batch_size=2)
+        fm, hm, info = parallel.split_frames(m, 2)
+        from deephar_amd import weights
+        tl = info['Tl']
+        packed = np.concatenate([fm.predict(clips[:, r * tl:(r + 1) * tl], batch_size=2) for r in range(2)], axis=1)
+        parts = [np.ascontiguousarray(packed[..., off:off + c]) for (_, off, c) in info['cut']]
+        head = hm.predict(parts, batch_size=2)
+        head = head if isinstance(head, list) else [head]
+        for k, ci in info['passthrough'].items():
+            assert np.array_equal(parts[ci], full[k]), (builder, 'passthrough', k)
+        for k, o in zip(info['head_outputs'], head):
+            assert np.array_equal(o, full[k]), (builder, 'head output', k)
+        # and the runtime class with a 1-rank group (gloo) drives the same two stages
+    import torch.distributed as dist
+    import os
+    if not dist.is_initialized():
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29533')
+        dist.init_process_group('gloo', rank=0, world_size=1)
+    try:
+        m, _ = _merge(2, 8, 16, 2, num_actions=15)
+        clips = np.random.default_rng(22).uniform(-1, 1, (1, 8, 256, 256, 3)).astype(np.float32)
+        outs = parallel.ShardedClipModel(m).predict(clips)
+        ref = m.predict(clips, batch_size=1)
+        assert all(np.array_equal(a, b) for a, b in zip(outs, ref))
+    finally:
+        dist.destroy_process_group()

@@ -1,0 +1,122 @@
+"""N>1 path on CPU: two gloo processes exercise the frame sharding, the packed all-gather and the head
+replication of deephar_amd.parallel with the CPU oracle standing in for the two HIP stages."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+T, J, BLOCKS, NACT = 4, 16, 2, 15
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _build():
+    from deephar_amd import graph, weights
+    from deephar_amd.models import reception, action
+    graph.reset_naming()
+    pe = reception.build((64, 64, 3), J, dim=2, num_blocks=BLOCKS, num_context_per_joint=2, ksize=(5, 5))
+    m = action.build_merge_model(pe, NACT, (64, 64, 3), T, J, BLOCKS, pose_dim=2, output_poses=True)
+    weights.init_synthetic(m, seed=0)
+    return m, weights.as_dict(m)
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    torch.set_num_threads(2)
+    try:
+        from deephar_amd import parallel
+        from oracle import action as oact
+        from oracle.naming import Weights
+        m, wd = _build()
+        W = Weights(wd)
+        clips = np.random.default_rng(5).uniform(-1, 1, (2, T, 64, 64, 3)).astype(np.float32)
+
+        def frame_fn(x_local):        # stand-in for the HIP frame stage: packed [N, T/G, J, 2+1+2+C]
+            n, tl = x_local.shape[:2]
+            W.reset()
+            with torch.no_grad():
+                y, p, f = oact.merge_frames(W, torch.from_numpy(x_local).reshape((n * tl,) + x_local.shape[2:]),
+                                            J, BLOCKS)
+            y, p, f = (v.reshape((n, tl) + tuple(v.shape[1:])) for v in (y, p, f))
+            return torch.cat([y, p, y * p, f], dim=-1)
+
+        def head_fn(parts):           # parts follow info['cut']: y, p, y*p, f
+            with torch.no_grad():
+                return [o.numpy() for o in oact.merge_head(W, parts[0], parts[1], parts[3], NACT)]
+
+        runner = parallel.ShardedClipModel(m, frame_fn=frame_fn, head_fn=head_fn)
+        assert runner.info['Tl'] == T // world and runner.info['packed_channels'] == 2 + 1 + 2 + 576
+        outs = runner.predict(clips)
+        ref = oact.forward_merge(wd, clips, NACT, J, BLOCKS, output_poses=True)
+        err = max(float(np.abs(a - b).max()) for a, b in zip(outs, ref))
+        lo, hi = parallel.shard_slice(7, rank, world)
+        q.put((rank, err, [o.shape for o in outs], (lo, hi)))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_frame_sharded_clip_model_two_ranks():
+    world, port = 2, _free_port()
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=500) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    res.sort()
+    for rank, err, shapes, sl in res:
+        assert err < 2e-5, 'rank %d: sharded result differs from the un-sharded oracle by %g' % (rank, err)
+        assert shapes[0] == (2, T, J, 2) and shapes[1] == (2, T, J, 1) and shapes[-1] == (2, NACT)
+    assert [r[3] for r in res] == [(0, 4), (4, 7)]
+
+
+def test_split_frames_partitions_merge_and_spnet():
+    from deephar_amd import graph, parallel
+    from deephar_amd.config import ModelConfig
+    from deephar_amd.models import spnet
+    from deephar_amd.utils import pa17j3d
+    m, _ = _build()
+    fm, hm, info = parallel.split_frames(m, 2)
+    assert fm.input_shape == (None, 2, 64, 64, 3) and fm.output_shape == (None, 2, J, 581)
+    assert info['passthrough'] == {0: 0, 1: 1} and info['head_outputs'] == list(range(2, 11))
+    kinds = {s.kind for s in hm.plan.steps}
+    assert 'dwconv' in kinds and 'kronecker' not in kinds          # pooling stays in the frame stage
+    assert all(s.kind != 'globalmaxmin' for s in fm.plan.steps)     # temporal heads stay in the head stage
+    # flops are conserved by the cut (frame stage scales with T/G)
+    full = m.plan.total_flops()
+    assert abs(2 * fm.plan.total_flops() + hm.plan.total_flops() - full) / full < 1e-6
+    with pytest.raises(ValueError):
+        parallel.split_frames(m, 3)
+    graph.reset_naming()
+    cfg = ModelConfig((8, 64, 64, 3), pa17j3d, num_actions=[60], num_pyramids=2, action_pyramids=[1, 2],
+                      num_levels=3, num_pose_features=64, num_visual_features=64)
+    sp = spnet.build(cfg)
+    fm, hm, info = parallel.split_frames(sp, 4)
+    assert fm.input_shape == (None, 2, 64, 64, 3)
+    assert sorted(info['passthrough']) == [0, 1, 2, 3] and info['head_outputs'] == [4, 5, 6, 7]
+    assert len(hm.inputs) == len(info['cut'])
+
+
+def test_shard_slice_covers_range():
+    from deephar_amd.parallel import shard_slice
+    for n in (0, 1, 7, 64, 65):
+        for w in (1, 2, 3, 8):
+            spans = [shard_slice(n, r, w) for r in range(w)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+            assert max(h - l for l, h in spans) - min(h - l for l, h in spans) <= 1
