@@ -82,6 +82,8 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-graph', action='store_true', help='launch kernels eagerly instead of hipGraph replay')
     ap.add_argument('--dump-steps', default=None, help='write the per-kernel profile (JSON) to this path')
+    ap.add_argument('--streams', type=int, default=None,
+                    help='HIP streams for independent model branches (default: the engine default)')
     ap.add_argument('--tune-cache', default=None,
                     help='JSON file with the autotuned conv tilings: loaded if present (no tuning launches, '
                          'keeps rocprofv3 kernel stats clean), written otherwise')
@@ -109,6 +111,8 @@ def main():
             dist.barrier()
 
     model = build_model(args.blocks)
+    if args.streams is not None:
+        model.num_streams = args.streams
     plan = model.plan
     ex = model.executor
     ex.use_graph = not args.no_graph
@@ -190,7 +194,7 @@ def main():
             'config': {'workload': 'MPII single-person 256x256, ReceptionNet %d blocks J=16 ctx=2 k=5, pose-only '
                                    'forward, batch=%d per GPU (BASELINE.json configs[1])' % (args.blocks, n),
                        'global_batch': world * n, 'parallelism': 'frame-shard x%d (no collective)' % world,
-                       'hipgraph': not args.no_graph, 'outputs_finite_in_range': ok},
+                       'hipgraph': not args.no_graph, 'streams': plan.nstreams, 'outputs_finite_in_range': ok},
             'roofline': {'bound': 'mfma', 'kernel': 'conv_igemm_kernel (all %d launches of one step)' % conv['launches'],
                          'achieved': round(achieved, 2), 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
                          'frac': round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), 'traffic': None,

@@ -77,6 +77,10 @@ SIGNATURES = {
     'dh_event_elapsed_ms': (C.c_int, [vp, vp, C.POINTER(C.c_float)]),
     'dh_event_destroy': (C.c_int, [vp]),
     'dh_stream_synchronize': (C.c_int, [vp]),
+    'dh_stream_create': (C.c_int, [C.POINTER(vp)]),
+    'dh_stream_destroy': (C.c_int, [vp]),
+    'dh_event_create_sync': (C.c_int, [C.POINTER(vp)]),
+    'dh_stream_wait_event': (C.c_int, [vp, vp]),
 }
 
 _lib = None

@@ -188,4 +188,23 @@ int dh_event_elapsed_ms(void* start, void* stop, float* ms_out) {
 int dh_event_destroy(void* event) { return rc_of(hipEventDestroy(reinterpret_cast<hipEvent_t>(event))); }
 int dh_stream_synchronize(void* stream) { return rc_of(hipStreamSynchronize(S(stream))); }
 
+int dh_stream_create(void** stream_out) {
+  if (stream_out == nullptr) return DH_EINVAL;
+  hipStream_t st;
+  if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) return DH_ELAUNCH;
+  *stream_out = st;
+  return DH_OK;
+}
+int dh_stream_destroy(void* stream) { return rc_of(hipStreamDestroy(S(stream))); }
+int dh_event_create_sync(void** event_out) {
+  if (event_out == nullptr) return DH_EINVAL;
+  hipEvent_t e;
+  if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return DH_ELAUNCH;
+  *event_out = e;
+  return DH_OK;
+}
+int dh_stream_wait_event(void* stream, void* event) {
+  return rc_of(hipStreamWaitEvent(S(stream), reinterpret_cast<hipEvent_t>(event), 0));
+}
+
 }  // extern "C"

@@ -84,6 +84,98 @@ __global__ __launch_bounds__(256) void dwconv_kernel(const DwArgs p) {
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// LDS-tiled depthwise conv for the large maps (W >= 16, C % 32 == 0): workgroup = (image, band of rows,
+// 32-channel chunk, full-width column tile).  The halo'd input tile is fetched from global ONCE (prologue
+// affine / ReLU / zero padding applied on the way in), every one of the KSxKS re-reads comes from LDS, the
+// filter taps of the chunk sit in LDS too.  Thread = (channel quad, 8-column strip, row).
+// ------------------------------------------------------------------------------------------------
+constexpr int DW_CQ = 8;        // channel quads per workgroup (32 channels)
+constexpr int DW_PITCH = 9;     // float4 per tile pixel (8 + 1 pad: spreads strips over LDS banks)
+
+template <int KS>
+__global__ __launch_bounds__(256) void dwconv_lds_kernel(const DwArgs p, const int tw, const int rows) {
+  extern __shared__ __attribute__((aligned(16))) float4 dsm[];
+  const int tid = threadIdx.x;
+  const int chunks = p.C / 32;
+  const int bands = (p.H + rows - 1) / rows;
+  const int ctiles = (p.W + tw - 1) / tw;
+  int b = blockIdx.x;
+  const int cchunk = b % chunks; b /= chunks;
+  const int ct = b % ctiles; b /= ctiles;
+  const int band = b % bands;
+  const int n = b / bands;
+  const int c0 = cchunk * 32, r0 = band * rows, w0 = ct * tw;
+  const int th = rows + KS - 1, twh = tw + KS - 1;
+  float4* tile = dsm;                               // [th][twh][DW_PITCH]
+  float4* wts = dsm + th * twh * DW_PITCH;          // [KS*KS][DW_CQ]
+  const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
+  const bool aff = p.pre_scale != nullptr;
+
+  for (int i = tid; i < KS * KS * DW_CQ; i += 256)
+    wts[i] = ld4(p.w + (size_t)(i / DW_CQ) * p.C + c0 + (i % DW_CQ) * 4);
+  const int q_in = tid & (DW_CQ - 1);
+  float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = zero;
+  if (aff) { sc = ld4(p.pre_scale + c0 + q_in * 4); sh = ld4(p.pre_shift + c0 + q_in * 4); }
+  const int npix = th * twh;
+  // all global loads of the tile are issued back to back (clamped addresses), then masked and stored:
+  // one HBM round trip per workgroup instead of one per loop iteration
+  constexpr int MAXL = 14;                          // ceil(12*36*8 / 256)
+  float4 stage[MAXL];
+  unsigned okmask = 0;
+#pragma unroll
+  for (int j = 0; j < MAXL; ++j) {                  // (tid + j*256) % 8 == tid % 8: the quad is fixed per thread
+    const int px = (tid + j * 256) / DW_CQ;
+    const int tr = px / twh, tc = px - tr * twh;
+    const int ih = r0 - p.PT + tr, iw = w0 - p.PL + tc;
+    const bool ok = px < npix && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
+    const size_t off = ok ? ((size_t)(n * p.H + ih) * p.W + iw) * p.ldx + c0 + q_in * 4 : 0;
+    stage[j] = ld4(p.x + off);
+    okmask |= (ok ? 1u : 0u) << j;
+  }
+#pragma unroll
+  for (int j = 0; j < MAXL; ++j) {
+    const int px = (tid + j * 256) / DW_CQ;
+    if (px >= npix) continue;
+    float4 v = stage[j];
+    if (aff) v = fma4(v, sc, sh);
+    if (p.pre_relu) v = max4(v, zero);
+    if (!((okmask >> j) & 1u)) v = zero;
+    tile[px * DW_PITCH + q_in] = v;
+  }
+  __syncthreads();
+
+  const int strips = tw >> 3;
+  const int q = tid & (DW_CQ - 1);
+  const int strip = (tid >> 3) % strips;
+  const int row = (tid >> 3) / strips;
+  if (row >= rows || r0 + row >= p.H) return;
+  float4 acc[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) acc[i] = zero;
+#pragma unroll
+  for (int kh = 0; kh < KS; ++kh) {
+    float4 wv[KS];
+#pragma unroll
+    for (int kw = 0; kw < KS; ++kw) wv[kw] = wts[(kh * KS + kw) * DW_CQ + q];
+    const float4* src = tile + ((row + kh) * twh + strip * 8) * DW_PITCH + q;
+#pragma unroll
+    for (int j = 0; j < 8 + KS - 1; ++j) {
+      const float4 v = src[j * DW_PITCH];
+#pragma unroll
+      for (int kw = 0; kw < KS; ++kw) {
+        const int o = j - kw;
+        if (o >= 0 && o < 8) acc[o] = fma4(v, wv[kw], acc[o]);
+      }
+    }
+  }
+  const int ow0 = w0 + strip * 8;
+  float* out = p.y + ((size_t)(n * p.H + r0 + row) * p.W + ow0) * p.ldy + c0 + q * 4;
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+    if (ow0 + i < p.W) st4(out + (size_t)i * p.ldy, acc[i]);
+}
+
 // Generic fallback (any KW, C not a multiple of 4): one thread per output element.
 __global__ __launch_bounds__(256) void dwconv_generic_kernel(const DwArgs p) {
   const long long total = (long long)p.N * p.H * p.W * p.C;
@@ -253,6 +345,20 @@ int launch_dwconv(const DwArgs& a, hipStream_t s) {
   if (a.N <= 0 || a.C <= 0 || a.KH <= 0 || a.KW <= 0) return DH_EINVAL;
   const bool vec = (a.C % 4 == 0) && (a.ldx % 4 == 0) && (a.ldy % 4 == 0) && al16(a.x) && al16(a.y) &&
                    al16(a.w) && (a.pre_scale == nullptr || (al16(a.pre_scale) && al16(a.pre_shift)));
+  if (vec && a.KH == a.KW && (a.KW == 5 || a.KW == 3) && a.C % 32 == 0 && a.W >= 32 && a.W % 8 == 0) {   // measured: pays from 32-wide maps up
+    // LDS-tiled path: column tile = min(W, 32), 8-column strips, rows chosen to fill 256 threads
+    const int tw = a.W >= 32 ? 32 : a.W;
+    int rows = 256 / (8 * (tw / 8));
+    if (rows > a.H) rows = a.H;
+    const long long blocks = (long long)a.N * ((a.H + rows - 1) / rows) * ((a.W + tw - 1) / tw) * (a.C / 32);
+    const size_t lds = ((size_t)(rows + a.KW - 1) * (tw + a.KW - 1) * DW_PITCH + (size_t)a.KW * a.KW * DW_CQ) * 16;
+    if (blocks <= 0x7fffffffLL && lds <= 64 * 1024 &&
+        (rows + a.KW - 1) * (tw + a.KW - 1) * DW_CQ <= 14 * 256) {
+      if (a.KW == 5) hipLaunchKernelGGL(dwconv_lds_kernel<5>, dim3((unsigned)blocks), dim3(256), lds, s, a, tw, rows);
+      else hipLaunchKernelGGL(dwconv_lds_kernel<3>, dim3((unsigned)blocks), dim3(256), lds, s, a, tw, rows);
+      return check_launch();
+    }
+  }
   if (vec && a.KH == a.KW && (a.KW == 5 || a.KW == 3 || a.KW == 1)) {
     const int TW = a.W >= 16 ? 8 : 4;
     const long long total = (long long)a.N * a.H * ((a.W + TW - 1) / TW) * (a.C / 4);

@@ -284,11 +284,53 @@ class BoundPlan:
             raise NotImplementedError('no binding for step kind %r' % k)
 
     # ---- execution -----------------------------------------------------------------------------------------
+    def _side_streams(self):
+        """Lazily created extra HIP streams + sync events for the parallel branches of the plan."""
+        if getattr(self, '_streams', None) is None:
+            lib = self.lib
+            self._streams, self._events, self._join, self._fork = [], {}, [], C.c_void_p()
+            for _ in range(self.plan.nstreams - 1):
+                st, ev = C.c_void_p(), C.c_void_p()
+                _lib.check(lib.dh_stream_create(C.byref(st)), 'stream create')
+                _lib.check(lib.dh_event_create_sync(C.byref(ev)), 'event create')
+                self._streams.append(st)
+                self._join.append(ev)
+            _lib.check(lib.dh_event_create_sync(C.byref(self._fork)), 'event create')
+            for i, (_, _, step) in enumerate(self.calls):
+                if step.record:
+                    ev = C.c_void_p()
+                    _lib.check(lib.dh_event_create_sync(C.byref(ev)), 'event create')
+                    self._events[i] = ev
+        return self._streams
+
     def launch_all(self, stream_ptr):
-        for fn, args, step in self.calls:
-            rc = fn(*args, stream_ptr)
+        """Enqueue the whole plan.  With one stream: plain in-order launches.  With several: steps go to
+        their scheduled stream, cross-stream dependencies become event waits, side streams fork from / join
+        back into `stream_ptr` (so the sequence is capturable into one hipGraph)."""
+        lib = self.lib
+        if self.plan.nstreams <= 1:
+            for fn, args, step in self.calls:
+                rc = fn(*args, stream_ptr)
+                if rc != 0:
+                    _lib.check(rc, 'step %s (%s)' % (step.kind, step.name))
+            return
+        side = self._side_streams()
+        ptrs = [stream_ptr] + [st for st in side]
+        _lib.check(lib.dh_event_record(self._fork, stream_ptr), 'fork')
+        for st in side:
+            _lib.check(lib.dh_stream_wait_event(st, self._fork), 'fork wait')
+        for i, (fn, args, step) in enumerate(self.calls):
+            sp = ptrs[step.stream]
+            for w in step.wait:
+                _lib.check(lib.dh_stream_wait_event(sp, self._events[w]), 'dependency wait')
+            rc = fn(*args, sp)
             if rc != 0:
                 _lib.check(rc, 'step %s (%s)' % (step.kind, step.name))
+            if step.record:
+                _lib.check(lib.dh_event_record(self._events[i], sp), 'event record')
+        for st, ev in zip(side, self._join):
+            _lib.check(lib.dh_event_record(ev, st), 'join record')
+            _lib.check(lib.dh_stream_wait_event(stream_ptr, ev), 'join wait')
 
     def capture(self, stream_ptr):
         lib = self.lib

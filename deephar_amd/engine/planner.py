@@ -60,6 +60,7 @@ class Value:
 
 class Step:
     def __init__(self, kind, ins, outs, attrs=None, params=None, name=None):
+        self.stream, self.deps, self.wait, self.record = 0, [], [], False   # filled by schedule.finalize
         self.kind = kind
         self.ins = ins          # dict role -> Value
         self.outs = outs        # dict role -> Value
@@ -98,6 +99,7 @@ class Plan:
         self.bufs = []
         self.arena_items = 0   # floats per batch item
         self.params = []       # ordered unique graph.Param list
+        self.nstreams = 1
 
     def total_flops(self, n=1):
         return sum(s.flops(n) for s in self.steps)
@@ -115,7 +117,8 @@ class _Lazy:
 
 
 class Planner:
-    def __init__(self, inputs, outputs):
+    def __init__(self, inputs, outputs, nstreams=1):
+        self.nstreams = nstreams
         self.g_inputs = inputs
         self.g_outputs = outputs
         self.nodes = G.topo_nodes(outputs)
@@ -216,8 +219,8 @@ class Planner:
             v.buf.pinned = True
             self.plan.outputs.append(v)
         self._collect_params()
-        self._lifetimes()
-        self._allocate()
+        from . import schedule
+        schedule.finalize(self.plan, self.nstreams)
         return self.plan
 
     # ---- element-wise laziness (R1) --------------------------------------------------------------------
@@ -577,41 +580,6 @@ class Planner:
                         out.append(p)
         self.plan.params = out
 
-    def _lifetimes(self):
-        for i, s in enumerate(self.plan.steps):
-            for v in list(s.ins.values()) + list(s.outs.values()):
-                if v is None:
-                    continue
-                b = v.buf
-                if b.start is None:
-                    b.start = i
-                b.end = i
-        last = len(self.plan.steps)
-        for b in self.plan.bufs:
-            if b.kind == 'input':
-                b.start = -1
-                if b.end is None:
-                    b.end = -1
-            if b.start is None:          # never touched (e.g. an output that is an input)
-                b.start, b.end = 0, last
-            if b.pinned:
-                b.end = last
 
-    def _allocate(self):
-        """Offline interval packing: largest buffers first, lowest non-conflicting offset."""
-        placed = []
-        for b in sorted(self.plan.bufs, key=lambda b: -b.items):
-            conflicts = sorted((p.offset, p.offset + p.items) for p in placed
-                               if not (p.end < b.start or b.end < p.start))
-            off = 0
-            for lo, hi in conflicts:
-                if off + b.items <= lo:
-                    break
-                off = max(off, hi)
-            b.offset = off
-            placed.append(b)
-        self.plan.arena_items = max((b.offset + b.items for b in self.plan.bufs), default=0)
-
-
-def build_plan(inputs, outputs):
-    return Planner(inputs, outputs).run()
+def build_plan(inputs, outputs, nstreams=1):
+    return Planner(inputs, outputs, nstreams).run()

@@ -27,6 +27,7 @@ class Model:
         self.trainable = True
         self._plan = None
         self._exec = None
+        self.num_streams = int(__import__('os').environ.get('DEEPHAR_STREAMS', '1'))
         # validates connectivity early (raises like Keras' "graph disconnected")
         self._nodes = G.topo_nodes(self.outputs)
         reach = {t.uid for t in self.inputs}
@@ -152,7 +153,7 @@ class Model:
     def plan(self):
         if self._plan is None:
             from .engine.planner import build_plan
-            self._plan = build_plan(self.inputs, self.outputs)
+            self._plan = build_plan(self.inputs, self.outputs, nstreams=self.num_streams)
         return self._plan
 
     @property

@@ -197,6 +197,13 @@ int dh_event_synchronize(void* event);
 int dh_event_elapsed_ms(void* start, void* stop, float* ms_out);
 int dh_event_destroy(void* event);
 int dh_stream_synchronize(void* stream);
+/* extra non-blocking streams + cross-stream ordering, so independent branches of a model can be captured as
+ * parallel branches of one hipGraph (fork: side stream waits on an event of the origin stream; join: origin waits
+ * on an event recorded at the tail of every side stream) */
+int dh_stream_create(void** stream_out);
+int dh_stream_destroy(void* stream);
+int dh_event_create_sync(void** event_out); /* hipEventDisableTiming */
+int dh_stream_wait_event(void* stream, void* event);
 
 #ifdef __cplusplus
 }
