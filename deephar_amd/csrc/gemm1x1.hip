@@ -22,7 +22,39 @@ constexpr int BK = 32;
 typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 
-template <int WM, int WN, int TM, int TN, bool UP2>
+// Fragment reads go through inline asm on purpose: with an LDS-DMA in flight hipcc cannot prove that the DMA's
+// LDS destination (the other stage) does not alias an ordinary ds_read and puts `s_waitcnt vmcnt(0)` in front
+// of the first fragment read of every K-step, which serialises the DMA with the MFMA block it is meant to
+// overlap.  An asm ds_read is invisible to that pass; its completion is awaited by hand (lgkm_wait) and the
+// consumers are fenced behind the wait with sched_barrier (hipcc would otherwise hoist the MFMAs).
+template <int OFF>
+__device__ __forceinline__ float4 lds_rd(unsigned addr) {
+  float4 v;
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
+  return v;
+}
+__device__ __forceinline__ void lgkm_wait() {
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_sched_barrier(0);
+}
+// (an asm v_max_f32 would save the canonicalising max fmaxf implies, but hipcc pads no VALU->MFMA hazard
+// wait states after inline asm -- measured wrong results)
+__device__ __forceinline__ float4 relu4(float4 v) {
+  return make_float4(fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f));
+}
+
+template <int TM, int TN, int BN, int BOFF, int S>
+__device__ __forceinline__ void fetch_frags(const unsigned (&a_addr)[TM][4], unsigned b_addr, float4 (&fa)[TM],
+                                            float4 (&fb)[TN]) {
+  fa[0] = lds_rd<0>(a_addr[0][S]);
+  if constexpr (TM > 1) fa[1] = lds_rd<0>(a_addr[1][S]);
+  constexpr int BO = BOFF + S * 2 * BN * 16;
+  fb[0] = lds_rd<BO>(b_addr);
+  if constexpr (TN > 1) fb[1] = lds_rd<BO + 512>(b_addr);
+  if constexpr (TN > 2) fb[2] = lds_rd<BO + 1024>(b_addr);
+}
+
+template <int WM, int WN, int TM, int TN, bool UP2, bool RELU>
 __global__ __launch_bounds__(WM* WN * 64, 2) void gemm1x1_kernel(const ConvArgs p, const int epi_vec) {
   constexpr int NT = WM * WN * 64;
   constexpr int BM = WM * TM * 32;
@@ -95,46 +127,74 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void gemm1x1_kernel(const ConvArgs 
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
 
-  // fragment read offsets (floats) inside a stage, per A tile row block
-  int a_off[TM];
+  // ---- fragment read addresses (LDS byte offsets), stage 0; tile row blocks start at multiples of 32 so
+  // (row & 7) == (lane & 7) and the XOR swizzle only depends on the lane
+  const unsigned lds0 = (unsigned)(uintptr_t)(lptr_t)smem;
+  unsigned a_base[TM][4];
 #pragma unroll
-  for (int i = 0; i < TM; ++i) a_off[i] = ((wm * TM + i) * 32 + li) * BK;
-  const int sw = li & 7;   // (row & 7) of this lane's rows: tile row blocks start at multiples of 32
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      a_base[i][q] = lds0 + (unsigned)(((wm * TM + i) * 32 + li) * BK * 4 + (((q * 2 + lh) ^ (li & 7)) << 4));
+  const unsigned b_base = lds0 + (unsigned)((lh * BN + wn * TN * 32 + li) * 16);
+  constexpr int BOFF = BM * BK * 4;   // B tile follows the A tile inside a stage
 
+  auto mfma_block = [&](const float4 (&a)[TM], const float4 (&b)[TN]) {
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].x, b[j].x, acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].y, b[j].y, acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].z, b[j].z, acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].w, b[j].w, acc[i][j], 0, 0, 0);
+      }
+  };
+  auto relu_frags = [&](float4 (&a)[TM]) {
+    if constexpr (RELU) {
+#pragma unroll
+      for (int i = 0; i < TM; ++i) a[i] = relu4(a[i]);
+    }
+  };
+
+  // NB: an asm ds_read result must be awaited inside the basic block that issued it -- register copies the
+  // allocator inserts at block boundaries (loop back-edge, if/else joins) would otherwise copy registers the
+  // data has not reached yet.  Hence every fetch and its wait live in the straight-line body of one K-step.
+  // (Fetching tile kt+1's first fragments before the loop back-edge was tried: correct with a tail wait, but
+  // the loop-carried fragment registers cost more than the hidden LDS latency buys: 111 vs 118 TFLOP/s.)
   for (int kt = 0; kt < nk; ++kt) {
     const int cur = kt & 1;
-    if (kt + 1 < nk) issue(kt + 1, cur ^ 1);
-    const float* sA = smem + cur * STAGE;
-    const float* sB = sA + BM * BK;
-    // fragments of sub-step s+1 are fetched from LDS while the MFMAs of sub-step s run (register double buffer)
-    float4 fa[2][TM], fb[2][TN];
-    auto fetch = [&](int s, float4 (&a)[TM], float4 (&b)[TN]) {
+    if (kt + 1 < nk) issue(kt + 1, cur ^ 1);          // DMA of the next tile flies during this MFMA block
+    const unsigned so = (unsigned)(cur * STAGE * 4);
+    unsigned a_addr[TM][4];
 #pragma unroll
-      for (int i = 0; i < TM; ++i) {
-        a[i] = *reinterpret_cast<const float4*>(&sA[a_off[i] + (((s * 2 + lh) ^ sw) << 2)]);
-        if (p.pre_relu) {
-          a[i].x = fmaxf(a[i].x, 0.f); a[i].y = fmaxf(a[i].y, 0.f);
-          a[i].z = fmaxf(a[i].z, 0.f); a[i].w = fmaxf(a[i].w, 0.f);
-        }
-      }
+    for (int i = 0; i < TM; ++i)
 #pragma unroll
-      for (int j = 0; j < TN; ++j)
-        b[j] = *reinterpret_cast<const float4*>(&sB[((s * 2 + lh) * BN + (wn * TN + j) * 32 + li) * 4]);
-    };
-    fetch(0, fa[0], fb[0]);
-#pragma unroll
-    for (int s = 0; s < 4; ++s) {
-      if (s + 1 < 4) fetch(s + 1, fa[(s + 1) & 1], fb[(s + 1) & 1]);
-#pragma unroll
-      for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[s & 1][i].x, fb[s & 1][j].x, acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[s & 1][i].y, fb[s & 1][j].y, acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[s & 1][i].z, fb[s & 1][j].z, acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[s & 1][i].w, fb[s & 1][j].w, acc[i][j], 0, 0, 0);
-        }
-    }
+      for (int q = 0; q < 4; ++q) a_addr[i][q] = a_base[i][q] + so;
+    const unsigned b_addr = b_base + so;
+
+    // sub-step s+1's fragments are in flight (asm ds_read) while sub-step s's MFMAs run
+    float4 fa0[TM], fb0[TN], fa1[TM], fb1[TN];
+    fetch_frags<TM, TN, BN, BOFF, 0>(a_addr, b_addr, fa0, fb0);
+    lgkm_wait();
+    fetch_frags<TM, TN, BN, BOFF, 1>(a_addr, b_addr, fa1, fb1);
+    __builtin_amdgcn_sched_barrier(0);   // keep the reads ahead of the MFMAs they overlap with
+    relu_frags(fa0);
+    mfma_block(fa0, fb0);
+    lgkm_wait();
+    fetch_frags<TM, TN, BN, BOFF, 2>(a_addr, b_addr, fa0, fb0);
+    __builtin_amdgcn_sched_barrier(0);
+    relu_frags(fa1);
+    mfma_block(fa1, fb1);
+    lgkm_wait();
+    fetch_frags<TM, TN, BN, BOFF, 3>(a_addr, b_addr, fa1, fb1);
+    __builtin_amdgcn_sched_barrier(0);
+    relu_frags(fa0);
+    mfma_block(fa0, fb0);
+    lgkm_wait();
+    relu_frags(fa1);
+    mfma_block(fa1, fb1);
+
     // tile kt+1 has landed (this wave's DMA) and every wave is done reading tile kt
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -143,37 +203,39 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void gemm1x1_kernel(const ConvArgs 
   conv_epilogue<WM, WN, TM, TN, UP2>(p, acc, smem, m0, n0, M, epi_vec);
 }
 
-template <int WM, int WN, int TM, int TN>
-int launch_cfg(const ConvArgs& a, int epi, hipStream_t s) {
+template <int WM, int WN, int TM, int TN, bool UP2, bool RELU>
+int launch_variant(const ConvArgs& a, int epi, unsigned tiles, hipStream_t s) {
   constexpr int BM = WM * TM * 32, BN = WN * TN * 32, NT = WM * WN * 64;
-  const long long M = (long long)a.N * a.OH * a.OW;
-  const long long tiles = ((M + BM - 1) / BM) * ((a.Cout + BN - 1) / BN);
-  if (tiles <= 0 || tiles > 0x7fffffffLL) return DH_EINVAL;
   constexpr int kStage = 2 * (BM * BK + BK * BN), kEpi = WM * WN * 32 * (TN * 32 + 4);
   constexpr size_t lds = (size_t)(kStage > kEpi ? kStage : kEpi) * sizeof(float);
   static_assert(lds <= 160 * 1024, "LDS budget");
+  auto kern = gemm1x1_kernel<WM, WN, TM, TN, UP2, RELU>;
+  if (lds > 64 * 1024) {
+    static bool once = (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                            (int)lds), true);
+    (void)once;
+  }
+  hipLaunchKernelGGL(kern, dim3(tiles), dim3(NT), lds, s, a, epi);
+  return check_launch();
+}
+
+template <int WM, int WN, int TM, int TN>
+int launch_cfg(const ConvArgs& a, int epi, hipStream_t s) {
+  constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
+  const long long M = (long long)a.N * a.OH * a.OW;
+  const long long tiles = ((M + BM - 1) / BM) * ((a.Cout + BN - 1) / BN);
+  if (tiles <= 0 || tiles > 0x7fffffffLL) return DH_EINVAL;
+  const unsigned t = (unsigned)tiles;
   if (a.up2) {
     if constexpr (TM * TN >= 6) {
       return DH_EUNSUPPORTED;
     } else {
-      auto kern = gemm1x1_kernel<WM, WN, TM, TN, true>;
-      if (lds > 64 * 1024) {
-        static bool once = (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                                (int)lds), true);
-        (void)once;
-      }
-      hipLaunchKernelGGL(kern, dim3((unsigned)tiles), dim3(NT), lds, s, a, epi);
+      return a.pre_relu ? launch_variant<WM, WN, TM, TN, true, true>(a, epi, t, s)
+                        : launch_variant<WM, WN, TM, TN, true, false>(a, epi, t, s);
     }
-  } else {
-    auto kern = gemm1x1_kernel<WM, WN, TM, TN, false>;
-    if (lds > 64 * 1024) {
-      static bool once = (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                              (int)lds), true);
-      (void)once;
-    }
-    hipLaunchKernelGGL(kern, dim3((unsigned)tiles), dim3(NT), lds, s, a, epi);
   }
-  return check_launch();
+  return a.pre_relu ? launch_variant<WM, WN, TM, TN, false, true>(a, epi, t, s)
+                    : launch_variant<WM, WN, TM, TN, false, false>(a, epi, t, s);
 }
 
 }  // namespace

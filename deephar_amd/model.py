@@ -27,7 +27,9 @@ class Model:
         self.trainable = True
         self._plan = None
         self._exec = None
-        self.num_streams = int(__import__('os').environ.get('DEEPHAR_STREAMS', '1'))
+        # independent branches run on parallel hipGraph branches (engine/schedule.py); >2 streams crashes
+        # hipStreamEndCapture in ROCm 7.2's runtime on this graph shape, so 2 is the default and the cap
+        self.num_streams = min(2, int(__import__('os').environ.get('DEEPHAR_STREAMS', '2')))
         # validates connectivity early (raises like Keras' "graph disconnected")
         self._nodes = G.topo_nodes(self.outputs)
         reach = {t.uid for t in self.inputs}
