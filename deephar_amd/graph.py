@@ -48,6 +48,7 @@ class Layer:
         self.scope = scope
         self.params = params    # list[Param] in Keras `layer.weights` order
         self.trainable = True
+        self.uid = next(_uid)   # creation order (= the reference's source order inside a builder)
 
     @property
     def weights(self):

@@ -1,0 +1,183 @@
+#!/usr/bin/env python
+"""Golden vectors from the reference's OWN model code (this container only; /root/reference is not on the GPU box).
+
+The reference's builders (deephar/layers.py, activations.py, models/*.py) are imported unmodified and executed on
+oracle/refrun/minikeras.py, a PyTorch-CPU stand-in for the few Keras/TF entry points they use.  Weights are the
+product's deterministic synthetic weights, handed to the reference model layer by layer (by name where the
+reference names its layers, by creation order inside each nested Model otherwise -- the same rule Keras'
+load_weights uses), so a wiring or ordering difference between the product builders and the reference shows up
+either as a shape mismatch here or as a numeric mismatch in tests/test_reference_golden.py.
+
+    python tests/golden/make_reference_golden.py        ->  tests/golden/reference_models.npz
+"""
+import importlib
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+REF = '/root/reference'
+OUT = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'reference_models.npz')
+
+from oracle.refrun import minikeras as mk   # noqa: E402
+
+
+def load_reference():
+    mk.install()
+    pkg = types.ModuleType('deephar')
+    pkg.__path__ = [REF + '/deephar']        # do not execute deephar/__init__.py (it imports the data loaders)
+    sys.modules['deephar'] = pkg
+    mods = {}
+    for name in ('layers', 'activations', 'config', 'models.blocks', 'models.reception', 'models.action',
+                 'models.common', 'models.spnet'):
+        mods[name] = importlib.import_module('deephar.' + name)
+    return mods
+
+
+def _scopes(model):
+    """{scope name: [weight layers in creation order]} for the nested Models of a mini-keras model; '' = top level."""
+    reg = {id(l): i for i, l in enumerate(mk.weight_layers())}
+    out = {'': []}
+
+    def unwrap(l):
+        return l.layer if isinstance(l, mk.TimeDistributed) else l
+
+    def walk(m, scope):
+        for l in m.layers:
+            l = unwrap(l)
+            if isinstance(l, mk.Model):
+                walk(l, l.name)
+            elif l.weights:
+                out.setdefault(scope, [])
+                if l not in out[scope]:
+                    out[scope].append(l)
+    walk(model, '')
+    for k in out:
+        out[k].sort(key=lambda l: reg[id(l)])
+    return out
+
+
+def transfer_weights(product_model, ref_model):
+    """Hand the product's weights to the reference model; returns the number of tensors set."""
+    by_scope = {}
+    for n in product_model._nodes:
+        for layer in n.layers.values():
+            lst = by_scope.setdefault(layer.scope, [])
+            if layer not in lst:
+                lst.append(layer)
+    ref_scopes = _scopes(ref_model)
+    count = 0
+    for scope, players in by_scope.items():
+        players.sort(key=lambda l: l.uid)
+        rlayers = ref_scopes.get(scope)
+        assert rlayers is not None, 'reference model has no nested model %r' % scope
+        rnames = {l.name: l for l in rlayers}
+        if all(pl.name in rnames for pl in players):
+            pairs = [(pl, rnames[pl.name]) for pl in players]            # explicit names (SPNet, sepconv_l*)
+        else:
+            # auto-named layers: creation order inside the nested model, frozen helper layers have no weights in
+            # the product and never appear in a scope that has product layers
+            assert len(players) == len(rlayers), (scope, len(players), len(rlayers),
+                                                  [l.name for l in players], [l.name for l in rlayers])
+            pairs = list(zip(players, rlayers))
+        for pl, rl in pairs:
+            rl.set_weights([p.value for p in pl.params])     # shape-checked inside
+            count += len(pl.params)
+    return count
+
+
+def run_both(ref_model, x):
+    outs = {}
+    for tag, dt in (('f32', torch.float32), ('f64', torch.float64)):
+        mk.set_dtype(dt)
+        for l in mk.weight_layers():          # re-cast the weights
+            l.weights = [w.to(dt) for w in l.weights]
+        y = ref_model.predict(x.astype(np.float64 if dt == torch.float64 else np.float32))
+        outs[tag] = y if isinstance(y, list) else [y]
+    mk.set_dtype(torch.float32)
+    return outs
+
+
+def main():
+    from deephar_amd import graph, weights
+    from deephar_amd import config as pconfig
+    from deephar_amd import utils as putils
+    from deephar_amd.models import reception as prec, action as pact, spnet as pspn
+    R = load_reference()
+    g = {}
+
+    def record(tag, ref_model, product_model, x):
+        weights.init_synthetic(product_model, seed=0)
+        n = transfer_weights(product_model, ref_model)
+        assert n == len(product_model.params), (tag, n, len(product_model.params))
+        outs = run_both(ref_model, x)
+        for k, arrs in outs.items():
+            for i, a in enumerate(arrs):
+                g['%s/%s/%d' % (tag, k, i)] = a.astype(np.float64 if k == 'f64' else np.float32)
+        g['%s/nout' % tag] = np.array(len(outs['f64']))
+        print(tag, 'outputs', [a.shape for a in outs['f64']], 'weights set', n)
+
+    def draw(tag, shape):
+        """inputs are not stored: tests regenerate them from the tag (tests/refgolden.py: case_input)"""
+        seed = int.from_bytes(tag.encode(), 'little') % (2 ** 31)
+        return np.random.default_rng(seed).uniform(-1, 1, shape)
+
+    # --- ReceptionNet 2-D with context (cfg 1/2 family), 2 blocks
+    mk.reset(); graph.reset_naming()
+    kw = dict(num_context_per_joint=2, num_blocks=2, ksize=(5, 5), concat_pose_confidence=False)
+    ref = R['models.reception'].build((256, 256, 3), 16, dim=2, **kw)
+    prod = prec.build((256, 256, 3), 16, dim=2, **kw)
+    x = draw('rec2d', (2, 256, 256, 3))
+    record('rec2d', ref, prod, x)
+
+    # --- ReceptionNet 3-D (cfg 3 family), 2 blocks, with exported heat-maps
+    mk.reset(); graph.reset_naming()
+    kw = dict(num_blocks=2, depth_maps=16, ksize=(5, 5), export_heatmaps=True)
+    ref = R['models.reception'].build((256, 256, 3), 17, dim=3, **kw)
+    prod = prec.build((256, 256, 3), 17, dim=3, **kw)
+    x = draw('rec3d', (2, 256, 256, 3))
+    record('rec3d', ref, prod, x)
+
+    # --- merge action model, 2-D v1 (cfg 4 family) and 3-D v2
+    for tag, dim, J, ver in (('merge2d', 2, 16, 'v1'), ('merge3d', 3, 20, 'v2')):
+        mk.reset(); graph.reset_naming()
+        T = 4
+        if dim == 2:
+            pe_kw = dict(num_context_per_joint=2, num_blocks=2, ksize=(5, 5))
+        else:
+            pe_kw = dict(num_blocks=2, depth_maps=8, ksize=(5, 5))
+        ref_pe = R['models.reception'].build((128, 128, 3), J, dim=dim, **pe_kw)
+        ref = R['models.action'].build_merge_model(ref_pe, 15, (128, 128, 3), T, J, 2, pose_dim=dim, depth_maps=8,
+                                                   pose_net_version=ver, output_poses=True)
+        prod_pe = prec.build((128, 128, 3), J, dim=dim, **pe_kw)
+        prod = pact.build_merge_model(prod_pe, 15, (128, 128, 3), T, J, 2, pose_dim=dim, depth_maps=8,
+                                      pose_net_version=ver, output_poses=True)
+        x = draw(tag, (2, T, 128, 128, 3))
+        record(tag, ref, prod, x)
+
+    # --- SPNet: NTU-like 3-D (T=4, time_stride 1) and Penn-like 2-D (T=16, time_stride 2, frame/joint padding)
+    for tag, T, lay, nact, pyr, apyr, feats, res in (('spnet3d', 4, 'pa17j3d', 60, 2, [1, 2], 192, 128),
+                                                    ('spnet2d', 16, 'pa16j2d', 15, 2, [2], 160, 128)):
+        mk.reset(); graph.reset_naming()
+        R['models.spnet'].__dict__.pop('act_cnt', None)       # the reference's process-global counter
+        rcfg = R['config'].ModelConfig((T, res, res, 3), getattr(putils, lay), num_actions=[nact], num_pyramids=pyr,
+                                       action_pyramids=apyr, num_levels=4, pose_replica=False,
+                                       num_pose_features=feats, num_visual_features=feats)
+        ref = R['models.spnet'].build(rcfg)
+        pcfg = pconfig.ModelConfig((T, res, res, 3), getattr(putils, lay), num_actions=[nact], num_pyramids=pyr,
+                                   action_pyramids=apyr, num_levels=4, pose_replica=False, num_pose_features=feats,
+                                   num_visual_features=feats)
+        prod = pspn.build(pcfg)
+        x = draw(tag, (1, T, res, res, 3))
+        record(tag, ref, prod, x)
+
+    np.savez_compressed(OUT, **g)
+    print('wrote', OUT, '%.1f MB' % (os.path.getsize(OUT) / 1e6))
+
+
+if __name__ == '__main__':
+    main()

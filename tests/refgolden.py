@@ -1,0 +1,69 @@
+"""Shared description of the golden cases produced by tests/golden/make_reference_golden.py (the reference's own
+model code executed on oracle/refrun/minikeras.py in the build container)."""
+import os
+
+import numpy as np
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'reference_models.npz')
+
+
+def case_input(tag, shape):
+    seed = int.from_bytes(tag.encode(), 'little') % (2 ** 31)
+    return np.random.default_rng(seed).uniform(-1, 1, shape)
+
+
+def golden(tag):
+    g = np.load(GOLDEN)
+    n = int(g['%s/nout' % tag])
+    return [g['%s/f32/%d' % (tag, i)] for i in range(n)], [g['%s/f64/%d' % (tag, i)] for i in range(n)]
+
+
+def build_case(tag):
+    """-> (product model with synthetic weights, input array float64, callable running the CPU oracle(dtype))"""
+    import torch
+    from deephar_amd import graph, weights, utils
+    from deephar_amd.config import ModelConfig
+    from deephar_amd.models import reception, action, spnet
+    from oracle import reception as oref, action as oact, spnet as osp
+    graph.reset_naming()
+    if tag == 'rec2d':
+        kw = dict(num_context_per_joint=2, num_blocks=2, ksize=(5, 5), concat_pose_confidence=False)
+        m = reception.build((256, 256, 3), 16, dim=2, **kw)
+        x = case_input(tag, (2, 256, 256, 3))
+        run = lambda wd, dt: oref.forward(wd, x, 16, 2, dtype=dt, **kw)
+    elif tag == 'rec3d':
+        kw = dict(num_blocks=2, depth_maps=16, ksize=(5, 5), export_heatmaps=True)
+        m = reception.build((256, 256, 3), 17, dim=3, **kw)
+        x = case_input(tag, (2, 256, 256, 3))
+        run = lambda wd, dt: oref.forward(wd, x, 17, 3, dtype=dt, **kw)
+    elif tag in ('merge2d', 'merge3d'):
+        dim, J, ver = (2, 16, 'v1') if tag == 'merge2d' else (3, 20, 'v2')
+        pe_kw = dict(num_context_per_joint=2, num_blocks=2, ksize=(5, 5)) if dim == 2 else \
+            dict(num_blocks=2, depth_maps=8, ksize=(5, 5))
+        pe = reception.build((128, 128, 3), J, dim=dim, **pe_kw)
+        m = action.build_merge_model(pe, 15, (128, 128, 3), 4, J, 2, pose_dim=dim, depth_maps=8,
+                                     pose_net_version=ver, output_poses=True)
+        x = case_input(tag, (2, 4, 128, 128, 3))
+        okw = dict(pose_dim=dim, depth_maps=8, pose_net_version=ver, output_poses=True,
+                   num_context_per_joint=2 if dim == 2 else 0)
+        run = lambda wd, dt: oact.forward_merge(wd, x, 15, J, 2, dtype=dt, **okw)
+    elif tag in ('spnet3d', 'spnet2d'):
+        T, lay, nact, pyr, apyr, feats = (4, 'pa17j3d', 60, 2, [1, 2], 192) if tag == 'spnet3d' else \
+            (16, 'pa16j2d', 15, 2, [2], 160)
+        layout = getattr(utils, lay)
+        cfg = ModelConfig((T, 128, 128, 3), layout, num_actions=[nact], num_pyramids=pyr, action_pyramids=apyr,
+                          num_levels=4, pose_replica=False, num_pose_features=feats, num_visual_features=feats)
+        m = spnet.build(cfg)
+        x = case_input(tag, (1, T, 128, 128, 3))
+        ocfg = dict(num_joints=layout.num_joints, dim=layout.dim, num_actions=[nact], num_pyramids=pyr,
+                    action_pyramids=apyr, num_levels=4, kernel_size=(5, 5), growth=96, image_div=8,
+                    num_pose_features=feats, num_visual_features=feats, sam_alpha=1)
+        run = lambda wd, dt: osp.forward(wd, x, ocfg, dtype=dt)
+    else:
+        raise KeyError(tag)
+    weights.init_synthetic(m, seed=0)
+    wd = weights.as_dict(m)
+    return m, x, (lambda dt: run(wd, dt))
+
+
+CASES = ['rec2d', 'rec3d', 'merge2d', 'merge3d', 'spnet3d', 'spnet2d']

@@ -276,3 +276,28 @@ def test_frame_sharded_stages_match_full_model(hip_lib, cuda):
         assert all(np.array_equal(a, b) for a, b in zip(outs, ref))
     finally:
         dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('tag', ['rec2d', 'rec3d', 'merge2d', 'merge3d', 'spnet3d', 'spnet2d'])
+def test_hip_matches_reference_code_goldens(tag, hip_lib, cuda):
+    """HIP engine vs the committed golden vectors that were computed by the reference's OWN model code
+    (tests/golden/make_reference_golden.py): coordinates within max(1e-3 px, 3 x the fp32 error of that same code),
+    identical arg-max action labels."""
+    import sys, os
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from refgolden import build_case, golden
+    m, x, _ = build_case(tag)
+    g32, g64 = golden(tag)
+    hip = m.predict(x.astype(np.float32), batch_size=len(x))
+    hip = hip if isinstance(hip, list) else [hip]
+    assert [h.shape for h in hip] == [g.shape for g in g64]
+    for k, (h, a, b) in enumerate(zip(hip, g32, g64)):
+        is_scores = b.ndim == 2 and tag.startswith(('merge', 'spnet'))
+        is_maps = b.ndim == 4 and tag == 'rec3d'
+        if is_scores:
+            _check('%s.act%d' % (tag, k), h, a, b, 1e-5)
+            assert np.array_equal(h.argmax(-1), b.argmax(-1))
+        elif is_maps:
+            _check('%s.maps%d' % (tag, k), h, a, b, 2e-5, rel=True)
+        else:
+            _check('%s.out%d' % (tag, k), h, a, b, PX_TOL if b.shape[-1] != 1 else 1e-5, rel=(b.shape[-1] == 1))
