@@ -1,0 +1,702 @@
+"""Minimal read-only HDF5 parser -- just enough for Keras `save_weights` / `model.save` files.
+
+The reference loads its published weights with `model.load_weights('weights_*.h5')`
+(exp/mpii/eval_mpii_singleperson.py:54, exp/pennaction/eval_penn_multitask.py:76); h5py is not available to
+the main interpreter of this image, so the subset of the HDF5 file format those files use is read here in
+pure Python + NumPy:
+
+  superblock v0/v1 (h5py default) and v2/v3; object headers v1 and v2 (+ continuation blocks);
+  old-style groups (symbol-table message -> v1 B-tree -> SNOD nodes + local heap) and compact new-style
+  groups (link messages); datasets with contiguous, compact or chunked (v1 B-tree; optional deflate /
+  shuffle filters) layout; attribute messages v1-v3; datatypes: IEEE floats, integers, fixed-length strings,
+  variable-length strings (global heap).
+
+Not supported (raises HDF5Error): dense link / attribute storage (fractal heaps), virtual / external storage,
+compound and reference types, v4 layout messages with non-B-tree-v1 chunk indices.  Keras weight files need none.
+Format reference: the public "HDF5 File Format Specification Version 3.0".
+"""
+import struct
+import zlib
+
+import numpy as np
+
+SIGNATURE = b'\x89HDF\r\n\x1a\n'
+UNDEF = 0xFFFFFFFFFFFFFFFF
+
+
+class HDF5Error(IOError):
+    pass
+
+
+class _Reader:
+    def __init__(self, buf):
+        self.buf = buf
+        self.O = 8   # size of offsets
+        self.L = 8   # size of lengths
+
+    def u(self, pos, n):
+        return int.from_bytes(self.buf[pos:pos + n], 'little')
+
+    def off(self, pos):
+        return self.u(pos, self.O)
+
+    def len_(self, pos):
+        return self.u(pos, self.L)
+
+
+def _pad8(n):
+    return (n + 7) & ~7
+
+
+class _Datatype:
+    def __init__(self, cls, size, np_dtype=None, vlen_string=False, base=None):
+        self.cls, self.size, self.np_dtype, self.vlen_string, self.base = cls, size, np_dtype, vlen_string, base
+
+
+def _parse_datatype(buf, pos):
+    """-> (_Datatype, bytes consumed)"""
+    b0 = buf[pos]
+    cls, ver = b0 & 0x0F, b0 >> 4
+    bits0 = buf[pos + 1]
+    size = int.from_bytes(buf[pos + 4:pos + 8], 'little')
+    order = '>' if (bits0 & 1) else '<'
+    if cls == 0:      # fixed point
+        signed = bool(bits0 & 0x08)
+        return _Datatype(cls, size, np.dtype('%s%s%d' % (order, 'i' if signed else 'u', size))), 8 + 4
+    if cls == 1:      # floating point
+        if size not in (2, 4, 8):
+            raise HDF5Error('unsupported float size %d' % size)
+        return _Datatype(cls, size, np.dtype('%sf%d' % (order, size))), 8 + 12
+    if cls == 3:      # fixed-length string
+        return _Datatype(cls, size, np.dtype('S%d' % size)), 8
+    if cls == 9:      # variable length
+        is_str = (bits0 & 0x0F) == 1
+        base, n = _parse_datatype(buf, pos + 8)
+        return _Datatype(cls, size, None, vlen_string=is_str, base=base), 8 + n
+    raise HDF5Error('unsupported HDF5 datatype class %d (version %d)' % (cls, ver))
+
+
+def _parse_dataspace(r, pos):
+    ver = r.buf[pos]
+    rank = r.buf[pos + 1]
+    flags = r.buf[pos + 2]
+    if ver == 1:
+        p = pos + 8
+    elif ver == 2:
+        if r.buf[pos + 3] == 2:       # null dataspace
+            return None
+        p = pos + 4
+    else:
+        raise HDF5Error('unsupported dataspace message version %d' % ver)
+    dims = tuple(r.len_(p + i * r.L) for i in range(rank))
+    return dims
+
+
+class _Object:
+    """Parsed object header: list of (type, flags, payload offset, payload size)."""
+
+    def __init__(self, f, addr):
+        self.f, self.addr = f, addr
+        self.msgs = []
+        r = f._r
+        buf = r.buf
+        if buf[addr:addr + 4] == b'OHDR':
+            self._parse_v2(addr)
+        else:
+            if buf[addr] != 1:
+                raise HDF5Error('bad object header at %d' % addr)
+            nmsg = r.u(addr + 2, 2)
+            hsize = r.u(addr + 8, 4)
+            self._parse_v1_block(addr + 16, hsize, [nmsg])
+
+    def _parse_v1_block(self, pos, size, left):
+        r = self.f._r
+        end = pos + size
+        while pos + 8 <= end and left[0] > 0:
+            mtype = r.u(pos, 2)
+            msize = r.u(pos + 2, 2)
+            mflags = r.buf[pos + 4]
+            data = pos + 8
+            left[0] -= 1
+            if mtype == 0x10:
+                self._parse_v1_block(r.off(data), r.len_(data + r.O), left)
+            else:
+                self.msgs.append((mtype, mflags, data, msize))
+            pos = data + msize
+
+    def _parse_v2(self, addr):
+        r = self.f._r
+        flags = r.buf[addr + 5]
+        p = addr + 6
+        if flags & 0x20:
+            p += 16
+        if flags & 0x10:
+            p += 4
+        n = 1 << (flags & 3)
+        size0 = r.u(p, n)
+        p += n
+        self._parse_v2_block(p, size0, flags)
+
+    def _parse_v2_block(self, pos, size, hflags):
+        r = self.f._r
+        end = pos + size
+        hdr = 4 + (2 if hflags & 0x04 else 0)
+        while pos + hdr <= end:
+            mtype = r.buf[pos]
+            msize = r.u(pos + 1, 2)
+            mflags = r.buf[pos + 3]
+            data = pos + hdr
+            if mtype == 0x10:
+                caddr, clen = r.off(data), r.len_(data + r.O)
+                if r.buf[caddr:caddr + 4] != b'OCHK':
+                    raise HDF5Error('bad continuation block')
+                self._parse_v2_block(caddr + 4, clen - 8, hflags)
+            elif mtype != 0:
+                self.msgs.append((mtype, mflags, data, msize))
+            pos = data + msize
+
+    def find(self, mtype):
+        return [(d, s, fl) for (t, fl, d, s) in self.msgs if t == mtype]
+
+
+class _Attrs:
+    def __init__(self, obj):
+        self._obj = obj
+        self._cache = None
+
+    def _load(self):
+        if self._cache is not None:
+            return self._cache
+        f = self._obj.f
+        r = f._r
+        out = {}
+        if self._obj.find(0x15):
+            info = self._obj.find(0x15)[0][0]
+            flags = r.buf[info + 1]
+            p = info + 2 + (2 if flags & 1 else 0)
+            if r.off(p) != UNDEF:
+                raise HDF5Error('dense attribute storage is not supported')
+        for (d, s, fl) in self._obj.find(0x0C):
+            ver = r.buf[d]
+            nsz, dsz, ssz = r.u(d + 2, 2), r.u(d + 4, 2), r.u(d + 6, 2)
+            if ver == 1:
+                p = d + 8
+                name = bytes(r.buf[p:p + nsz]).split(b'\0')[0].decode('utf8')
+                p += _pad8(nsz)
+                dt, _ = _parse_datatype(r.buf, p)
+                p += _pad8(dsz)
+                dims = _parse_dataspace(r, p)
+                p += _pad8(ssz)
+            elif ver in (2, 3):
+                p = d + 8 + (1 if ver == 3 else 0)
+                name = bytes(r.buf[p:p + nsz]).split(b'\0')[0].decode('utf8')
+                p += nsz
+                dt, _ = _parse_datatype(r.buf, p)
+                p += dsz
+                dims = _parse_dataspace(r, p)
+                p += ssz
+            else:
+                raise HDF5Error('unsupported attribute message version %d' % ver)
+            out[name] = f._read_values(dt, dims, p)
+        self._cache = out
+        return out
+
+    def __getitem__(self, k):
+        return self._load()[k]
+
+    def __contains__(self, k):
+        return k in self._load()
+
+    def keys(self):
+        return self._load().keys()
+
+    def get(self, k, default=None):
+        return self._load().get(k, default)
+
+
+class Dataset:
+    def __init__(self, f, obj, name):
+        self._f, self._obj, self.name = f, obj, name
+        r = f._r
+        self._dt, _ = _parse_datatype(r.buf, obj.find(0x03)[0][0])
+        self.shape = _parse_dataspace(r, obj.find(0x01)[0][0])
+        self.attrs = _Attrs(obj)
+
+    @property
+    def dtype(self):
+        return self._dt.np_dtype
+
+    def __array__(self, dtype=None, copy=None):
+        a = np.asarray(self.read())
+        return a.astype(dtype) if dtype is not None else a
+
+    def __getitem__(self, idx):
+        return self.read()[idx]
+
+    def read(self):
+        f, r = self._f, self._f._r
+        (d, s, _), = self._obj.find(0x08)[:1]
+        ver = r.buf[d]
+        dt = self._dt
+        shape = self.shape if self.shape is not None else (0,)
+        count = int(np.prod(shape, dtype=np.int64)) if shape else 1
+        if ver == 3 or ver == 4:
+            cls = r.buf[d + 1]
+            if cls == 0:
+                size = r.u(d + 2, 2)
+                return f._decode(dt, shape, bytes(r.buf[d + 4:d + 4 + size]))
+            if cls == 1:
+                addr = r.off(d + 2)
+                if addr == UNDEF:
+                    return np.zeros(shape, dt.np_dtype)
+                return f._read_values(dt, shape, addr)
+            if cls == 2 and ver == 3:
+                ndim = r.buf[d + 2]
+                bt = r.off(d + 3)
+                p = d + 3 + r.O
+                cdims = [r.u(p + 4 * i, 4) for i in range(ndim)]
+                return self._read_chunked(bt, cdims[:-1], shape)
+            raise HDF5Error('unsupported data layout class %d (message v%d)' % (cls, ver))
+        if ver in (1, 2):
+            ndim, cls = r.buf[d + 1], r.buf[d + 2]
+            p = d + 8
+            if cls == 1:
+                return f._read_values(dt, shape, r.off(p))
+            if cls == 2:
+                bt = r.off(p)
+                p += r.O
+                cdims = [r.u(p + 4 * i, 4) for i in range(ndim)]
+                return self._read_chunked(bt, cdims[:-1], shape)
+            if cls == 0:
+                p += 4 * ndim
+                size = r.u(p, 4)
+                return f._decode(dt, shape, bytes(r.buf[p + 4:p + 4 + size]))
+        raise HDF5Error('unsupported data layout message version %d' % ver)
+
+    def _filters(self):
+        r = self._f._r
+        out = []
+        for (d, s, _) in self._obj.find(0x0B):
+            ver, n = r.buf[d], r.buf[d + 1]
+            p = d + (8 if ver == 1 else 2)
+            for _i in range(n):
+                fid = r.u(p, 2)
+                if ver == 1 or fid >= 256:
+                    nlen = r.u(p + 2, 2)
+                    ncv = r.u(p + 6, 2)
+                    p += 8 + (_pad8(nlen) if ver == 1 else nlen)
+                else:
+                    ncv = r.u(p + 4, 2)
+                    p += 6
+                cvals = [r.u(p + 4 * i, 4) for i in range(ncv)]
+                p += 4 * ncv
+                if ver == 1 and ncv % 2:
+                    p += 4
+                out.append((fid, cvals))
+        return out
+
+    def _read_chunked(self, btree, cdims, shape):
+        f, r = self._f, self._f._r
+        dt = self._dt
+        if dt.np_dtype is None:
+            raise HDF5Error('chunked variable-length data is not supported')
+        out = np.zeros(shape, dt.np_dtype)
+        if btree == UNDEF:
+            return out
+        filters = self._filters()
+        nd = len(shape)
+        csize = int(np.prod(cdims)) * dt.size
+
+        def visit(addr):
+            if r.buf[addr:addr + 4] != b'TREE' or r.buf[addr + 4] != 1:
+                raise HDF5Error('bad chunk B-tree node')
+            level = r.buf[addr + 5]
+            n = r.u(addr + 6, 2)
+            p = addr + 8 + 2 * r.O
+            ksz = 8 + 8 * (nd + 1)
+            for _i in range(n):
+                nbytes = r.u(p, 4)
+                mask = r.u(p + 4, 4)
+                offs = [r.u(p + 8 + 8 * k, 8) for k in range(nd)]
+                child = r.off(p + ksz)
+                if level > 0:
+                    visit(child)
+                else:
+                    raw = bytes(r.buf[child:child + nbytes])
+                    for k, (fid, cv) in reversed(list(enumerate(filters))):
+                        if mask & (1 << k):
+                            continue
+                        if fid == 1:
+                            raw = zlib.decompress(raw)
+                        elif fid == 2:
+                            es = cv[0] if cv else dt.size
+                            a = np.frombuffer(raw, np.uint8).reshape(es, -1)
+                            raw = a.T.tobytes()
+                        elif fid == 3:
+                            raw = raw[:-4]   # fletcher32 checksum, not verified
+                        else:
+                            raise HDF5Error('unsupported HDF5 filter id %d' % fid)
+                    chunk = np.frombuffer(raw[:csize], dt.np_dtype).reshape(cdims)
+                    sl_out = tuple(slice(o, min(o + c, s)) for o, c, s in zip(offs, cdims, shape))
+                    sl_in = tuple(slice(0, s.stop - s.start) for s in sl_out)
+                    out[sl_out] = chunk[sl_in]
+                p += ksz + r.O
+        visit(btree)
+        return out
+
+
+class Group:
+    def __init__(self, f, obj, name):
+        self._f, self._obj, self.name = f, obj, name
+        self.attrs = _Attrs(obj)
+        self._links = None
+
+    def _load(self):
+        if self._links is not None:
+            return self._links
+        f, r = self._f, self._f._r
+        links = {}
+        for (d, s, _) in self._obj.find(0x11):          # symbol table message
+            bt, heap = r.off(d), r.off(d + r.O)
+            if r.buf[heap:heap + 4] != b'HEAP':
+                raise HDF5Error('bad local heap')
+            hdata = r.off(heap + 8 + 2 * r.L)
+
+            def visit(addr):
+                if r.buf[addr:addr + 4] != b'TREE' or r.buf[addr + 4] != 0:
+                    raise HDF5Error('bad group B-tree node')
+                level = r.buf[addr + 5]
+                n = r.u(addr + 6, 2)
+                p = addr + 8 + 2 * r.O + r.L
+                for _i in range(n):
+                    child = r.off(p)
+                    p += r.O + r.L
+                    if level > 0:
+                        visit(child)
+                        continue
+                    if r.buf[child:child + 4] != b'SNOD':
+                        raise HDF5Error('bad symbol table node')
+                    ns = r.u(child + 6, 2)
+                    q = child + 8
+                    for _j in range(ns):
+                        noff = r.off(q)
+                        oaddr = r.off(q + r.O)
+                        e = r.buf.find(b'\0', hdata + noff)
+                        links[bytes(r.buf[hdata + noff:e]).decode('utf8')] = oaddr
+                        q += 2 * r.O + 24
+            visit(bt)
+        for (d, s, _) in self._obj.find(0x02):          # link info: dense storage?
+            flags = r.buf[d + 1]
+            p = d + 2 + (8 if flags & 1 else 0)
+            if r.off(p) != UNDEF:
+                raise HDF5Error('dense link storage (fractal heap) is not supported; re-save the file with '
+                                'h5py libver="earliest"')
+        for (d, s, _) in self._obj.find(0x06):          # link message
+            flags = r.buf[d + 1]
+            p = d + 2
+            ltype = 0
+            if flags & 0x08:
+                ltype = r.buf[p]
+                p += 1
+            if flags & 0x04:
+                p += 8
+            if flags & 0x10:
+                p += 1
+            n = 1 << (flags & 3)
+            nlen = r.u(p, n)
+            p += n
+            name = bytes(r.buf[p:p + nlen]).decode('utf8')
+            p += nlen
+            if ltype == 0:
+                links[name] = r.off(p)
+        self._links = links
+        return links
+
+    def keys(self):
+        return list(self._load().keys())
+
+    def __iter__(self):
+        return iter(self.keys())
+
+    def __contains__(self, path):
+        try:
+            self[path]
+            return True
+        except KeyError:
+            return False
+
+    def __getitem__(self, path):
+        if isinstance(path, bytes):
+            path = path.decode('utf8')
+        node = self
+        if path.startswith('/'):
+            node = self._f
+        for part in [p for p in path.split('/') if p]:
+            if not isinstance(node, Group):
+                raise KeyError(path)
+            links = node._load()
+            if part not in links:
+                raise KeyError('%s (no "%s" in %s)' % (path, part, node.name))
+            node = node._f._open(links[part], (node.name.rstrip('/') + '/' + part))
+        return node
+
+
+class File(Group):
+    """`File(path)` -- read-only; behaves like the h5py subset Keras' loader uses: `f.attrs[...]`,
+    `f['group/sub/dataset']`, `'model_weights' in f`, `np.asarray(dataset)`."""
+
+    def __init__(self, path):
+        with open(path, 'rb') as fh:
+            buf = fh.read()
+        base = -1
+        for cand in (0, 512, 1024, 2048, 4096):
+            if buf[cand:cand + 8] == SIGNATURE:
+                base = cand
+                break
+        if base < 0:
+            raise HDF5Error('%s is not an HDF5 file' % path)
+        self.filename = path
+        self._r = r = _Reader(buf)
+        self._objs = {}
+        ver = buf[base + 8]
+        if ver in (0, 1):
+            r.O, r.L = buf[base + 13], buf[base + 14]
+            p = base + 24 + (4 if ver == 1 else 0)
+            p += 4 * r.O                      # base, free-space, eof, driver
+            root_addr = r.off(p + r.O)        # root symbol-table entry: name offset, header address
+        elif ver in (2, 3):
+            r.O, r.L = buf[base + 9], buf[base + 10]
+            p = base + 12
+            root_addr = r.off(p + 3 * r.O)
+        else:
+            raise HDF5Error('unsupported superblock version %d' % ver)
+        if r.O != 8 or r.L != 8:
+            if r.O not in (4, 8) or r.L not in (4, 8):
+                raise HDF5Error('unsupported offset/length sizes')
+        Group.__init__(self, self, _Object(self, root_addr), '/')
+
+    def _open(self, addr, name):
+        if addr not in self._objs:
+            obj = _Object(self, addr)
+            self._objs[addr] = Dataset(self, obj, name) if obj.find(0x08) else Group(self, obj, name)
+        return self._objs[addr]
+
+    def close(self):
+        pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        return False
+
+    # ---- value decoding -------------------------------------------------------------------------------
+    def _read_values(self, dt, dims, addr):
+        r = self._r
+        count = int(np.prod(dims, dtype=np.int64)) if dims else 1
+        if dims is None:
+            return None
+        if dt.np_dtype is not None:
+            a = np.frombuffer(r.buf, dt.np_dtype, count=count, offset=addr).reshape(dims if dims else ())
+            if dt.np_dtype.byteorder == '>':
+                a = a.astype(dt.np_dtype.newbyteorder('<'))
+            return a.copy() if dims else a[()]
+        return self._decode(dt, dims, r.buf[addr:addr + count * dt.size])
+
+    def _decode(self, dt, dims, raw):
+        count = int(np.prod(dims, dtype=np.int64)) if dims else 1
+        if dt.np_dtype is not None:
+            a = np.frombuffer(raw, dt.np_dtype, count=count).reshape(dims if dims else ())
+            if dt.np_dtype.byteorder == '>':
+                a = a.astype(dt.np_dtype.newbyteorder('<'))
+            return a.copy() if dims else a[()]
+        if dt.cls == 9 and dt.vlen_string:
+            r = self._r
+            vals = []
+            es = 4 + r.O + 4
+            for i in range(count):
+                n = int.from_bytes(raw[i * es:i * es + 4], 'little')
+                gaddr = int.from_bytes(raw[i * es + 4:i * es + 4 + r.O], 'little')
+                gidx = int.from_bytes(raw[i * es + 4 + r.O:i * es + es], 'little')
+                vals.append(self._global_heap_object(gaddr, gidx)[:n])
+            if not dims:
+                return vals[0]
+            out = np.empty(count, dtype=object)
+            out[:] = vals
+            return out.reshape(dims)
+        raise HDF5Error('unsupported variable-length datatype')
+
+    def _global_heap_object(self, addr, index):
+        r = self._r
+        if r.buf[addr:addr + 4] != b'GCOL':
+            raise HDF5Error('bad global heap collection')
+        size = r.len_(addr + 8)
+        p = addr + 8 + r.L
+        end = addr + size
+        while p + 8 + r.L <= end:
+            idx = r.u(p, 2)
+            osz = r.len_(p + 8)
+            if idx == 0:
+                break
+            if idx == index:
+                return bytes(r.buf[p + 8 + r.L:p + 8 + r.L + osz])
+            p += 8 + r.L + _pad8(osz)
+        raise HDF5Error('global heap object %d not found' % index)
+
+
+def is_hdf5(path):
+    try:
+        with open(path, 'rb') as fh:
+            return fh.read(8) == SIGNATURE
+    except OSError:
+        return False
+
+
+# =========================================================================================================
+# Minimal writer: old-style groups, contiguous float/int datasets, fixed-length-string / numeric attributes.
+# Produces files that h5py / libhdf5 open (superblock v0, v1 object headers) -- the layout Keras 2.1.4 files
+# have -- so `Model.save_weights('x.h5')` can hand weights back to the reference's own loader.
+# =========================================================================================================
+ATTRS = '@attrs'
+
+
+def _dtype_msg(dt):
+    dt = np.dtype(dt)
+    if dt.kind == 'f':
+        exp_bits, mant_bits, bias = {2: (5, 10, 15), 4: (8, 23, 127), 8: (11, 52, 1023)}[dt.itemsize]
+        head = bytes([0x11, 0x20, dt.itemsize * 8 - 1, 0x00]) + struct.pack('<I', dt.itemsize)
+        return head + struct.pack('<HHBBBBI', 0, dt.itemsize * 8, mant_bits, exp_bits, 0, mant_bits, bias)
+    if dt.kind in 'iu':
+        head = bytes([0x10, 0x08 if dt.kind == 'i' else 0x00, 0, 0]) + struct.pack('<I', dt.itemsize)
+        return head + struct.pack('<HH', 0, dt.itemsize * 8)
+    if dt.kind == 'S':
+        return bytes([0x13, 0x01, 0, 0]) + struct.pack('<I', max(dt.itemsize, 1))
+    raise HDF5Error('cannot write dtype %s' % dt)
+
+
+def _space_msg(shape):
+    if shape == ():
+        return struct.pack('<BBB5x', 1, 0, 0)
+    return struct.pack('<BBB5x', 1, len(shape), 0) + b''.join(struct.pack('<Q', s) for s in shape)
+
+
+def _msg(mtype, body):
+    body = body + b'\0' * (_pad8(len(body)) - len(body))
+    if len(body) > 0xFFFF:
+        raise HDF5Error('object header message too large (%d bytes): Keras 2.1.4 has the same 64 KB limit on '
+                        'layer_names / weight_names attributes' % len(body))
+    return struct.pack('<HHB3x', mtype, len(body), 0) + body
+
+
+def _attr_msg(name, value):
+    if isinstance(value, str):
+        value = value.encode('utf8')
+    if isinstance(value, (list, tuple)):
+        value = [v.encode('utf8') if isinstance(v, str) else v for v in value]
+        value = np.array(value) if len(value) else np.zeros((0,), np.float64)
+    a = np.asarray(value)
+    if a.dtype.kind == 'U':
+        a = a.astype('S')
+    if a.dtype.kind == 'S' and a.dtype.itemsize == 0:
+        a = a.astype('S1')
+    shape = a.shape                      # (np.ascontiguousarray would turn a scalar into shape (1,))
+    nm = name.encode('utf8') + b'\0'
+    dt, sp = _dtype_msg(a.dtype), _space_msg(shape)
+    pad = lambda b: b + b'\0' * (_pad8(len(b)) - len(b))
+    body = struct.pack('<BBHHH', 1, 0, len(nm), len(dt), len(sp)) + pad(nm) + pad(dt) + pad(sp) + a.tobytes()
+    return _msg(0x0C, body)
+
+
+class _Writer:
+    def __init__(self):
+        self.buf = bytearray(96)        # superblock, filled in last
+
+    def put(self, data):
+        while len(self.buf) % 8:
+            self.buf.append(0)
+        addr = len(self.buf)
+        self.buf += data
+        return addr
+
+    def header(self, msgs):
+        body = b''.join(msgs)
+        return self.put(struct.pack('<BBHII4x', 1, 0, len(msgs), 1, len(body)) + body)
+
+    def dataset(self, arr):
+        a = np.ascontiguousarray(arr)
+        if a.dtype.byteorder == '>':
+            a = a.astype(a.dtype.newbyteorder('<'))
+        raw = a.tobytes()
+        daddr = self.put(raw) if raw else UNDEF
+        msgs = [_msg(0x01, _space_msg(a.shape)), _msg(0x03, _dtype_msg(a.dtype)),
+                _msg(0x05, struct.pack('<BBBB', 2, 2, 2, 0)),
+                _msg(0x08, struct.pack('<BBQQ', 3, 1, daddr, len(raw)))]
+        return self.header(msgs)
+
+    def group(self, tree, leaf_k):
+        attrs = tree.get(ATTRS, {})
+        entries = []
+        for name in sorted(k for k in tree if k != ATTRS):       # symbol nodes are ordered by name
+            child = tree[name]
+            if isinstance(child, dict):
+                entries.append((name, ) + self.group(child, leaf_k))
+            else:
+                entries.append((name, self.dataset(child), None, None))
+        if len(entries) > 2 * leaf_k:
+            raise HDF5Error('group with %d members exceeds the symbol-node capacity' % len(entries))
+        heap = bytearray(8)
+        offs = []
+        for name, *_ in entries:
+            offs.append(len(heap))
+            nb = name.encode('utf8') + b'\0'
+            heap += nb + b'\0' * (_pad8(len(nb)) - len(nb))
+        free_off = len(heap)
+        heap += struct.pack('<QQ', 1, 16)       # one free block: next = 1 (none), size 16
+        hdata = self.put(bytes(heap))
+        haddr = self.put(b'HEAP' + struct.pack('<B3xQQQ', 0, len(heap), free_off, hdata))
+        snod = bytearray(b'SNOD' + struct.pack('<BBH', 1, 0, len(entries)))
+        for (name, oaddr, bt, hp), no in zip(entries, offs):
+            if bt is None:
+                snod += struct.pack('<QQII16x', no, oaddr, 0, 0)
+            else:
+                snod += struct.pack('<QQIIQQ', no, oaddr, 1, 0, bt, hp)
+        snod += b'\0' * (8 + 2 * leaf_k * 40 - len(snod))
+        saddr = self.put(bytes(snod))
+        tree_node = b'TREE' + struct.pack('<BBHQQ', 0, 0, 1 if entries else 0, UNDEF, UNDEF)
+        tree_node += struct.pack('<QQQ', 0, saddr, offs[-1] if offs else 0)
+        tree_node += b'\0' * (24 + 2 * 16 * 16 + 8 - len(tree_node))      # room for 2K = 32 children
+        baddr = self.put(tree_node)
+        msgs = [_msg(0x11, struct.pack('<QQ', baddr, haddr))] + [_attr_msg(k, v) for k, v in attrs.items()]
+        return self.header(msgs), baddr, haddr
+
+
+def _max_members(tree):
+    n = len([k for k in tree if k != ATTRS])
+    for k, v in tree.items():
+        if k != ATTRS and isinstance(v, dict):
+            n = max(n, _max_members(v))
+    return n
+
+
+def write_file(path, tree):
+    """tree: nested dict  name -> ndarray | dict; the special key '@attrs' maps attribute names to values
+    (bytes / str / numbers / lists of bytes / ndarrays).  '/' inside a name is NOT interpreted -- build the
+    nesting explicitly (see `put_path`)."""
+    w = _Writer()
+    leaf_k = max(4, (_max_members(tree) + 1) // 2)
+    root, bt, hp = w.group(tree, leaf_k)
+    eof = len(w.buf)
+    sb = SIGNATURE + struct.pack('<BBBBBBBBHHI', 0, 0, 0, 0, 0, 8, 8, 0, leaf_k, 16, 0)
+    sb += struct.pack('<QQQQ', 0, UNDEF, eof, UNDEF)
+    sb += struct.pack('<QQIIQQ', 0, root, 1, 0, bt, hp)
+    w.buf[:len(sb)] = sb
+    with open(path, 'wb') as fh:
+        fh.write(bytes(w.buf))
+
+
+def put_path(tree, path, value):
+    """tree['a']['b']['c'] = value for path 'a/b/c' (what h5py's create_dataset does with a nested name)."""
+    parts = [p for p in path.split('/') if p]
+    for p in parts[:-1]:
+        tree = tree.setdefault(p, {})
+    tree[parts[-1]] = value

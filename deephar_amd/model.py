@@ -14,6 +14,14 @@ import numpy as np
 from . import graph as G
 
 
+class CallRec:
+    """One call of a nested Model on new tensors (a Keras Node); kept on the cloned nodes so that
+    deephar_amd/keras_compat.py can rebuild the layer graph Keras would have seen."""
+
+    def __init__(self, model, inputs, outputs):
+        self.model, self.inputs, self.outputs = model, list(inputs), list(outputs)
+
+
 class Model:
     def __init__(self, inputs, outputs, name=None):
         self._single_in = not isinstance(inputs, (list, tuple))
@@ -125,6 +133,7 @@ class Model:
     def __call__(self, x):
         xs = list(x) if isinstance(x, (list, tuple)) else [x]
         outs = G.clone_subgraph(self.inputs, self.outputs, xs)
+        rec = CallRec(self, xs, outs)
         tagged = set()
         stack = [t.node for t in outs if t.node is not None]
         stop = {t.uid for t in xs}
@@ -134,6 +143,7 @@ class Model:
                 continue
             tagged.add(n.uid)
             n.attrs['_models'] = [self] + list(n.attrs.get('_models', []))
+            n.attrs['_calls'] = [rec] + list(n.attrs.get('_calls', []))
             for t in n.inputs:
                 if t.uid not in stop and t.node is not None:
                     stack.append(t.node)

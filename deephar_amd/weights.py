@@ -1,10 +1,10 @@
 """Weights: synthetic initialisation, .npz persistence, Keras-ordered import.
 
-The published Keras HDF5 weight files (exp/mpii/eval_mpii_singleperson.py:29-33 etc.) are not available
-offline and h5py is absent from the main interpreter; the native on-disk format here is
-.npz keyed by '<scope>/<layer>/<weight>'.  `load_weights` also accepts
-  * an .npz written by `tools/h5_to_npz.py` from a Keras `save_weights` file (keys 'h5:<idx>:<name>' in
-    Keras' topological weight order, or plain Keras weight names for by_name=True).
+Two on-disk formats:
+  * Keras 2.x HDF5 `save_weights` / `model.save` files, the format of the reference's published weights
+    (exp/mpii/eval_mpii_singleperson.py:29-33,54 etc.): read and written without h5py by deephar_amd/hdf5.py,
+    paired with the model in Keras' own layer / weight order or by layer name (deephar_amd/keras_compat.py);
+  * .npz keyed by '<scope>/<layer>/<weight>' (native, order-independent).
 Synthetic weights follow SURVEY.md 8d: He-normal conv kernels, randomised BN statistics, fixed seed.
 """
 import zlib
@@ -135,6 +135,10 @@ def as_dict(model):
 
 
 def save_weights(model, path):
+    if str(path).endswith(('.h5', '.hdf5')):
+        from . import keras_compat
+        keras_compat.save_hdf5(model, path)
+        return
     d = as_dict(model)
     missing = [k for k, v in d.items() if v is None]
     if missing:
@@ -143,12 +147,14 @@ def save_weights(model, path):
 
 
 def load_weights(model, path, by_name=False):
+    from . import hdf5
+    if hdf5.is_hdf5(path):
+        from . import keras_compat
+        keras_compat.load_hdf5(model, path, by_name=by_name)
+        return
     data = np.load(path)
     keys = list(data.keys())
     params = model.params
-    if keys and all(k.startswith('h5:') for k in keys):
-        _load_keras_order(params, data, keys, by_name)
-        return
     have = set(keys)
     missing = [p.key for p in params if p.key not in have]
     if missing and not by_name:
@@ -157,27 +163,3 @@ def load_weights(model, path, by_name=False):
     for p in params:
         if p.key in have:
             p.set(data[p.key])
-
-
-def _load_keras_order(params, data, keys, by_name):
-    """Keys 'h5:<idx>:<keras weight name>' as dumped by tools/h5_to_npz.py from layer_names/weight_names
-    order.  Frozen helper layers of the reference (soft-argmax convs, aggregation Dense: layers.py:180-194,
-    blocks.py:221-233) carry weights in the file but not in this engine; they are skipped by name."""
-    def is_frozen(name):
-        base = name.split('/')[-2] if '/' in name else name
-        return base.startswith('custom_sam_') or '_xy_' in base or base.startswith('dense_') or \
-            base.startswith('conv1d_')
-
-    ordered = sorted(keys, key=lambda k: int(k.split(':')[1]))
-    arrays = [(k.split(':', 2)[2], data[k]) for k in ordered if not is_frozen(k.split(':', 2)[2])]
-    if by_name:
-        byname = {n: a for n, a in arrays}
-        for p in params:
-            kn = '%s/%s:0' % (p.key.split('/')[-2], p.name)
-            if kn in byname:
-                p.set(byname[kn])
-        return
-    if len(arrays) != len(params):
-        raise ValueError('Keras file holds %d trainable tensors, model expects %d' % (len(arrays), len(params)))
-    for p, (n, a) in zip(params, arrays):
-        p.set(a)

@@ -90,9 +90,23 @@ def _apply(fn, x):
     return fn(x)
 
 
+class KNode:
+    """One call of a layer (keras.engine.topology.Node): who produced the inputs, what came out."""
+
+    def __init__(self, layer, inputs, outputs):
+        self.outbound_layer, self.input_tensors, self.output_tensors = layer, list(inputs), list(outputs)
+        layer.inbound_nodes.append(self)
+        for i, o in enumerate(self.output_tensors):
+            o._kh = (layer, len(layer.inbound_nodes) - 1, i)
+
+
 def Input(shape=None, name=None, **kw):
     t = KTensor(None, [], name)
     t._dummy = torch.zeros((1,) + tuple(shape), dtype=DTYPE[0])
+    lay = Layer.__new__(Layer)
+    lay.name = name or _auto_name('input')
+    lay.trainable, lay.weights, lay.built, lay.inbound_nodes = False, None, True, []
+    KNode(lay, [], [t])
     return t
 
 
@@ -102,9 +116,10 @@ class Layer:
 
     def __init__(self, name=None, **kw):
         self.name = name or _auto_name(self.prefix)
-        self.trainable = True
+        self.trainable = bool(kw.get('trainable', True))
         self.weights = None          # list of torch tensors once built
         self.built = False
+        self.inbound_nodes = []
 
     def build(self, x):
         pass
@@ -123,6 +138,7 @@ class Layer:
         out = _apply(self.compute, x)
         if isinstance(out, KTensor):
             out._layer = self
+            KNode(self, x if isinstance(x, (list, tuple)) else [x], [out])
         return out
 
     def get_weights(self):
@@ -280,7 +296,12 @@ class Lambda(Layer):
         self.function = function
 
     def __call__(self, x):
-        return self.function(x)      # K.* and operators are polymorphic: symbolic in, symbolic out
+        out = self.function(x)       # K.* and operators are polymorphic: symbolic in, symbolic out
+        if isinstance(out, KTensor):
+            if out is x or hasattr(out, '_kh'):
+                out = KTensor(lambda a: a, [out])
+            KNode(self, x if isinstance(x, (list, tuple)) else [x], [out])
+        return out
 
 
 class _Pool(Layer):
@@ -363,18 +384,22 @@ class TimeDistributed(Layer):
         return y.reshape((n, t) + tuple(y.shape[1:]))
 
 
-def _merge(fn):
+def _merge(prefix_, fn):
+    cls = type(prefix_.capitalize(), (Layer,), {'prefix': prefix_, 'compute': lambda self, v: fn(list(v))})
+
     def op(tensors, name=None, **kw):
-        return _apply(fn, list(tensors))
+        return cls(name=name)(list(tensors))
     return op
 
 
-add = _merge(lambda v: sum(v[1:], v[0]))
-multiply = _merge(lambda v: math.prod(v[1:], start=v[0]))
+add = _merge('add', lambda v: sum(v[1:], v[0]))
+multiply = _merge('multiply', lambda v: math.prod(v[1:], start=v[0]))
 
 
 def concatenate(tensors, axis=-1, name=None, **kw):
-    return _apply(lambda v: torch.cat(v, dim=axis), list(tensors))
+    lay = Layer(name=name or _auto_name('concatenate'))
+    lay.compute = lambda v: torch.cat(list(v), dim=axis)
+    return lay(list(tensors))
 
 
 # ------------------------------------------------------------------------------------------------- models
@@ -425,14 +450,17 @@ class Model(Layer):
 
     def __call__(self, x):
         out = _apply(self.compute, x)
+        xs = x if isinstance(x, (list, tuple)) else [x]
         if self._single_out:
             if isinstance(out, KTensor):
                 out._layer = self
+                KNode(self, xs, [out])
             return out
         if isinstance(out, KTensor):        # multi-output model called symbolically -> one KTensor per output
             outs = [KTensor((lambda v, i=i: v[i]), [out]) for i in range(len(self.outputs))]
             for o in outs:
                 o._layer = self
+            KNode(self, xs, outs)
             return outs
         return out
 
@@ -528,3 +556,98 @@ def install():
 
 def weight_layers():
     return list(_layer_registry)
+
+
+# ------------------------------------------------------------------------------- Keras topology emulation
+def keras_layers(model):
+    """`Model.layers` in Keras 2.1.4's order (keras/engine/topology.py, Container.__init__): depth-first walk
+    from the outputs numbers the layers (pre-order), node depths are longest paths to an output, a layer sits
+    at the largest depth of its nodes, layers are listed by decreasing depth then by traversal index.  This is
+    the order `save_weights` writes groups in and `load_weights` (by_name=False) consumes them."""
+    sys.setrecursionlimit(max(sys.getrecursionlimit(), 20000))
+    layer_index, order, finished = {}, [], set()
+
+    def visit(t):
+        layer, ni, _ = t._kh
+        node = layer.inbound_nodes[ni]
+        if id(node) in finished:
+            return
+        if id(layer) not in layer_index:
+            layer_index[id(layer)] = len(layer_index)
+        for it in node.input_tensors:
+            visit(it)
+        finished.add(id(node))
+        order.append(node)
+
+    for o in model.outputs:
+        visit(o)
+    node_depth, layer_depth, layers = {}, {}, {}
+    for node in reversed(order):
+        lay = node.outbound_layer
+        d = max(node_depth.setdefault(id(node), 0), layer_depth.get(id(lay), 0))
+        layer_depth[id(lay)] = d
+        layers[id(lay)] = lay
+        node_depth[id(node)] = d
+        for it in node.input_tensors:
+            il, ni, _ = it._kh
+            inode = il.inbound_nodes[ni]
+            node_depth[id(inode)] = max(d + 1, node_depth.get(id(inode), 0))
+    return sorted(layers.values(), key=lambda l: (-layer_depth[id(l)], layer_index[id(l)]))
+
+
+def _own_weights(layer):
+    """(trainable, non-trainable) lists of (suffix, index into layer.weights) for a leaf layer."""
+    n = len(layer.weights or [])
+    if isinstance(layer, BatchNormalization):
+        names = (['gamma'] if layer.scale else []) + ['beta', 'moving_mean', 'moving_variance']
+        tr = list(range(n - 2))
+        return [(names[i], i) for i in tr], [(names[i], i) for i in (n - 2, n - 1)]
+    names = {Conv2D: ['kernel'], Conv1D: ['kernel'], Dense: ['kernel'],
+             SeparableConv2D: ['depthwise_kernel', 'pointwise_kernel']}.get(type(layer), ['w%d' % i for i in range(n)])
+    return [(names[i], i) for i in range(n)], []
+
+
+def layer_weights(layer):
+    """`layer.weights` as Keras orders them: [(weight name, owner layer, index)], trainable first, then
+    non-trainable; frozen layers / frozen nested Models report everything as non-trainable (topology.py:
+    Layer.weights, Container.trainable_weights / non_trainable_weights, wrappers.py: Wrapper)."""
+    def tr(l):
+        if isinstance(l, TimeDistributed):
+            return tr(l.layer)
+        if not l.trainable:
+            return []
+        if isinstance(l, Model):
+            return [w for x in keras_layers(l) for w in tr(x)]
+        return [('%s/%s:0' % (l.name, s), l, i) for s, i in _own_weights(l)[0]] if l.weights else []
+
+    def ntr(l):
+        if isinstance(l, TimeDistributed):
+            return ntr(l.layer)
+        if isinstance(l, Model):
+            inner = keras_layers(l)
+            w = [w for x in inner for w in ntr(x)]
+            return w if l.trainable else [w_ for x in inner for w_ in tr(x)] + w
+        if not l.weights:
+            return []
+        t, n = _own_weights(l)
+        own = (n if l.trainable else t + n)
+        return [('%s/%s:0' % (l.name, s), l, i) for s, i in own]
+
+    return tr(layer) + ntr(layer)
+
+
+def save_layout(model):
+    """What `model.save_weights` puts in the HDF5 file: [(group name, [(dataset name, array)])] in file order,
+    weight-less layers included with an empty list (Keras writes an empty group for them)."""
+    out = []
+    for lay in keras_layers(model):
+        seen, ws = {}, []
+        for name, owner, i in layer_weights(lay):
+            k = seen.get(name, 0)
+            seen[name] = k + 1
+            if k:
+                head, tail = name.split('/', 1)
+                name = '%s_%d/%s' % (head, k, tail)
+            ws.append((name, owner.weights[i].detach().cpu().numpy()))
+        out.append((lay.name, ws))
+    return out

@@ -102,49 +102,35 @@ def run_both(ref_model, x):
     return outs
 
 
-def main():
-    from deephar_amd import graph, weights
+def draw(tag, shape):
+    """inputs are not stored: tests regenerate them from the tag (tests/refgolden.py: case_input)"""
+    seed = int.from_bytes(tag.encode(), 'little') % (2 ** 31)
+    return np.random.default_rng(seed).uniform(-1, 1, shape)
+
+
+TAGS = ('rec2d', 'rec3d', 'merge2d', 'merge3d', 'spnet3d', 'spnet2d')
+
+
+def build_pair(R, tag):
+    """(reference model on mini-keras, product model, input) for one golden case."""
+    from deephar_amd import graph
     from deephar_amd import config as pconfig
     from deephar_amd import utils as putils
     from deephar_amd.models import reception as prec, action as pact, spnet as pspn
-    R = load_reference()
-    g = {}
-
-    def record(tag, ref_model, product_model, x):
-        weights.init_synthetic(product_model, seed=0)
-        n = transfer_weights(product_model, ref_model)
-        assert n == len(product_model.params), (tag, n, len(product_model.params))
-        outs = run_both(ref_model, x)
-        for k, arrs in outs.items():
-            for i, a in enumerate(arrs):
-                g['%s/%s/%d' % (tag, k, i)] = a.astype(np.float64 if k == 'f64' else np.float32)
-        g['%s/nout' % tag] = np.array(len(outs['f64']))
-        print(tag, 'outputs', [a.shape for a in outs['f64']], 'weights set', n)
-
-    def draw(tag, shape):
-        """inputs are not stored: tests regenerate them from the tag (tests/refgolden.py: case_input)"""
-        seed = int.from_bytes(tag.encode(), 'little') % (2 ** 31)
-        return np.random.default_rng(seed).uniform(-1, 1, shape)
-
-    # --- ReceptionNet 2-D with context (cfg 1/2 family), 2 blocks
-    mk.reset(); graph.reset_naming()
-    kw = dict(num_context_per_joint=2, num_blocks=2, ksize=(5, 5), concat_pose_confidence=False)
-    ref = R['models.reception'].build((256, 256, 3), 16, dim=2, **kw)
-    prod = prec.build((256, 256, 3), 16, dim=2, **kw)
-    x = draw('rec2d', (2, 256, 256, 3))
-    record('rec2d', ref, prod, x)
-
-    # --- ReceptionNet 3-D (cfg 3 family), 2 blocks, with exported heat-maps
-    mk.reset(); graph.reset_naming()
-    kw = dict(num_blocks=2, depth_maps=16, ksize=(5, 5), export_heatmaps=True)
-    ref = R['models.reception'].build((256, 256, 3), 17, dim=3, **kw)
-    prod = prec.build((256, 256, 3), 17, dim=3, **kw)
-    x = draw('rec3d', (2, 256, 256, 3))
-    record('rec3d', ref, prod, x)
-
-    # --- merge action model, 2-D v1 (cfg 4 family) and 3-D v2
-    for tag, dim, J, ver in (('merge2d', 2, 16, 'v1'), ('merge3d', 3, 20, 'v2')):
-        mk.reset(); graph.reset_naming()
+    mk.reset()
+    graph.reset_naming()
+    if tag == 'rec2d':      # ReceptionNet 2-D with context (cfg 1/2 family), 2 blocks
+        kw = dict(num_context_per_joint=2, num_blocks=2, ksize=(5, 5), concat_pose_confidence=False)
+        ref = R['models.reception'].build((256, 256, 3), 16, dim=2, **kw)
+        prod = prec.build((256, 256, 3), 16, dim=2, **kw)
+        return ref, prod, draw(tag, (2, 256, 256, 3))
+    if tag == 'rec3d':      # ReceptionNet 3-D (cfg 3 family), 2 blocks, with exported heat-maps
+        kw = dict(num_blocks=2, depth_maps=16, ksize=(5, 5), export_heatmaps=True)
+        ref = R['models.reception'].build((256, 256, 3), 17, dim=3, **kw)
+        prod = prec.build((256, 256, 3), 17, dim=3, **kw)
+        return ref, prod, draw(tag, (2, 256, 256, 3))
+    if tag in ('merge2d', 'merge3d'):   # merge action model, 2-D v1 (cfg 4 family) and 3-D v2
+        dim, J, ver = (2, 16, 'v1') if tag == 'merge2d' else (3, 20, 'v2')
         T = 4
         if dim == 2:
             pe_kw = dict(num_context_per_joint=2, num_blocks=2, ksize=(5, 5))
@@ -156,25 +142,94 @@ def main():
         prod_pe = prec.build((128, 128, 3), J, dim=dim, **pe_kw)
         prod = pact.build_merge_model(prod_pe, 15, (128, 128, 3), T, J, 2, pose_dim=dim, depth_maps=8,
                                       pose_net_version=ver, output_poses=True)
-        x = draw(tag, (2, T, 128, 128, 3))
-        record(tag, ref, prod, x)
+        return ref, prod, draw(tag, (2, T, 128, 128, 3))
+    # SPNet: NTU-like 3-D (T=4, time_stride 1) and Penn-like 2-D (T=16, time_stride 2, frame/joint padding)
+    T, lay, nact, pyr, apyr, feats, res = {'spnet3d': (4, 'pa17j3d', 60, 2, [1, 2], 192, 128),
+                                           'spnet2d': (16, 'pa16j2d', 15, 2, [2], 160, 128)}[tag]
+    R['models.spnet'].__dict__.pop('act_cnt', None)       # the reference's process-global counter
+    rcfg = R['config'].ModelConfig((T, res, res, 3), getattr(putils, lay), num_actions=[nact], num_pyramids=pyr,
+                                   action_pyramids=apyr, num_levels=4, pose_replica=False,
+                                   num_pose_features=feats, num_visual_features=feats)
+    ref = R['models.spnet'].build(rcfg)
+    pcfg = pconfig.ModelConfig((T, res, res, 3), getattr(putils, lay), num_actions=[nact], num_pyramids=pyr,
+                               action_pyramids=apyr, num_levels=4, pose_replica=False, num_pose_features=feats,
+                               num_visual_features=feats)
+    prod = pspn.build(pcfg)
+    return ref, prod, draw(tag, (1, T, res, res, 3))
 
-    # --- SPNet: NTU-like 3-D (T=4, time_stride 1) and Penn-like 2-D (T=16, time_stride 2, frame/joint padding)
-    for tag, T, lay, nact, pyr, apyr, feats, res in (('spnet3d', 4, 'pa17j3d', 60, 2, [1, 2], 192, 128),
-                                                    ('spnet2d', 16, 'pa16j2d', 15, 2, [2], 160, 128)):
-        mk.reset(); graph.reset_naming()
-        R['models.spnet'].__dict__.pop('act_cnt', None)       # the reference's process-global counter
-        rcfg = R['config'].ModelConfig((T, res, res, 3), getattr(putils, lay), num_actions=[nact], num_pyramids=pyr,
-                                       action_pyramids=apyr, num_levels=4, pose_replica=False,
-                                       num_pose_features=feats, num_visual_features=feats)
-        ref = R['models.spnet'].build(rcfg)
-        pcfg = pconfig.ModelConfig((T, res, res, 3), getattr(putils, lay), num_actions=[nact], num_pyramids=pyr,
-                                   action_pyramids=apyr, num_levels=4, pose_replica=False, num_pose_features=feats,
-                                   num_visual_features=feats)
-        prod = pspn.build(pcfg)
-        x = draw(tag, (1, T, res, res, 3))
-        record(tag, ref, prod, x)
 
+def keras_file_layout(ref_model):
+    """What Keras' save_weights would write for the reference model (mini-keras' statement of Container.layers /
+    layer.weights order): [[group, [[dataset name, shape, crc32 of the float32 bytes], ...]], ...], weight-owning
+    groups only.  tests/test_keras_weights.py holds the product's own derivation (deephar_amd/keras_compat.py)
+    against this, frozen helper kernels included."""
+    import zlib
+    out = []
+    for name, ws in mk.save_layout(ref_model):
+        if ws:
+            out.append([name, [[wn, list(a.shape), zlib.crc32(np.ascontiguousarray(a, dtype=np.float32).tobytes())]
+                               for wn, a in ws]])
+    return out
+
+
+def check_weight_files(tag, ref_model, product_model):
+    """Both directions through real files: reference layout -> .h5 -> product.load_weights, and
+    product.save_weights(.h5) -> Keras-order assignment into the reference model."""
+    import tempfile
+    from deephar_amd import hdf5
+    by_name = tag.startswith('spnet')          # the reference loads SPNet files with by_name=True
+    want = {p.key: p.value.copy() for p in product_model.params}
+    with tempfile.TemporaryDirectory() as d:
+        rl = mk.save_layout(ref_model)
+        tree = {hdf5.ATTRS: {'layer_names': [n.encode() for n, _ in rl], 'backend': b'tensorflow',
+                             'keras_version': b'2.1.4'}}
+        for n, ws in rl:
+            sub = tree.setdefault(n, {})
+            for wn, a in ws:
+                hdf5.put_path(sub, wn, a.astype(np.float32))
+            sub[hdf5.ATTRS] = {'weight_names': [wn.encode() for wn, _ in ws]}
+        hdf5.write_file(d + '/ref.h5', tree)
+        for p in product_model.params:
+            p.value = None
+        product_model.load_weights(d + '/ref.h5', by_name=by_name)
+        bad = [p.key for p in product_model.params if p.value is None or not np.array_equal(p.value, want[p.key])]
+        assert not bad, (tag, 'reference file -> product', bad[:3])
+        if not by_name:
+            product_model.save_weights(d + '/prod.h5')
+            f = hdf5.File(d + '/prod.h5')
+            names = [n.decode() for n in f.attrs['layer_names']]
+            ref_groups = [(n, ws) for n, ws in rl if ws]
+            assert len(names) == len(ref_groups), (tag, len(names), len(ref_groups))
+            for name, (rn, ws) in zip(names, ref_groups):      # Keras pairs groups and layers by ORDER
+                wn = [w.decode() for w in f[name].attrs['weight_names']]
+                assert len(wn) == len(ws), (tag, name, rn)
+                for w, (_, a) in zip(wn, ws):
+                    assert np.array_equal(np.asarray(f[name][w]), a.astype(np.float32)), (tag, name, w)
+    print(tag, 'weight files: reference->product %s, product->reference %s' %
+          ('by name' if by_name else 'by order', 'n/a (by-name family)' if by_name else 'by order'))
+
+
+def main():
+    import json
+    from deephar_amd import weights
+    R = load_reference()
+    g = {}
+    layouts = {}
+    for tag in TAGS:
+        ref_model, product_model, x = build_pair(R, tag)
+        weights.init_synthetic(product_model, seed=0)
+        n = transfer_weights(product_model, ref_model)
+        assert n == len(product_model.params), (tag, n, len(product_model.params))
+        layouts[tag] = keras_file_layout(ref_model)
+        check_weight_files(tag, ref_model, product_model)
+        outs = run_both(ref_model, x)
+        for k, arrs in outs.items():
+            for i, a in enumerate(arrs):
+                g['%s/%s/%d' % (tag, k, i)] = a.astype(np.float64 if k == 'f64' else np.float32)
+        g['%s/nout' % tag] = np.array(len(outs['f64']))
+        print(tag, 'outputs', [a.shape for a in outs['f64']], 'weights set', n)
+    with open(os.path.join(os.path.dirname(OUT), 'keras_layouts.json'), 'w') as fh:
+        json.dump(layouts, fh, separators=(',', ':'))
     np.savez_compressed(OUT, **g)
     print('wrote', OUT, '%.1f MB' % (os.path.getsize(OUT) / 1e6))
 
