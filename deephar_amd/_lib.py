@@ -15,10 +15,10 @@ i32, i64, vp = C.c_int32, C.c_int64, C.c_void_p
 
 class ConvArgs(C.Structure):
     _fields_ = [(n, vp) for n in ('x', 'w', 'y', 'pre_scale', 'pre_shift', 'post_scale', 'post_shift',
-                                   'res1', 'res2')] + \
+                                   'res1', 'res2', 'in_lut')] + \
                [(n, i32) for n in ('N', 'H', 'W', 'Cin', 'ldx', 'OH', 'OW', 'Cout', 'ldy', 'KH', 'KW', 'SH',
                                    'SW', 'PT', 'PL', 'K', 'Kp', 'Np', 'ldr1', 'ldr2', 'pre_relu', 'post_relu',
-                                   'up2')]
+                                   'up2', 'x_u8')]
 
 
 class DwArgs(C.Structure):
@@ -54,6 +54,7 @@ SIGNATURES = {
     'dh_conv2d_num_tile_cfgs': (C.c_int, []),
     'dh_conv2d_pick_tile_cfg': (C.c_int, [C.c_int, C.c_int]),
     'dh_conv2d_f32': (C.c_int, [C.POINTER(ConvArgs), C.c_int, vp]),
+    'dh_normalize_u8_f32': (C.c_int, [vp, vp, vp, C.c_int64, C.c_int, vp]),
     'dh_dwconv2d_f32': (C.c_int, [C.POINTER(DwArgs), vp]),
     'dh_pool2d_f32': (C.c_int, [C.POINTER(PoolArgs), vp]),
     'dh_upsample2x_add_f32': (C.c_int, [vp, C.c_int, vp, C.c_int, vp, C.c_int] + [C.c_int] * 4 + [vp]),

@@ -92,6 +92,7 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void conv_igemm_kernel(const ConvAr
   float4 ra[APASS], rb[BPASS];
   float4 psc = make_float4(1.f, 1.f, 1.f, 1.f), psh = make_float4(0.f, 0.f, 0.f, 0.f);
   unsigned amask = 0;   // VEC4: bit ps ; scalar path: bit (ps*4 + e)
+  int lut_c[4] = {0, 0, 0, 0};   // scalar path with uint8 input: LUT row (channel * 256) of the staged elements
 
   // running decode of this thread's k index (k = kt*32 + a_col) into (kh, kw, c); VEC4 only
   int t_c = a_col % p.Cin, t_kw, t_kh;
@@ -135,12 +136,14 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void conv_igemm_kernel(const ConvAr
         const bool kv = k < p.K;
         sc[e] = has_pre ? p.pre_scale[cc] : 1.f;
         sh[e] = has_pre ? p.pre_shift[cc] : 0.f;
+        lut_c[e] = (kv ? cc : 0) * 256;
 #pragma unroll
         for (int ps = 0; ps < APASS; ++ps) {
           const int ih = a_ih0[ps] + kh, iw = a_iw0[ps] + kw;
           const bool ok = kv && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
           const size_t off = ok ? (size_t)(a_pix[ps] + ih * p.W + iw) * p.ldx + cc : 0;
-          (&ra[ps].x)[e] = p.x[off];
+          // uint8 frames: stage the raw byte (exact in fp32); the LUT is applied in store_tile()
+          (&ra[ps].x)[e] = p.x_u8 ? (float)reinterpret_cast<const unsigned char*>(p.x)[off] : p.x[off];
           amask |= (ok ? 1u : 0u) << (ps * 4 + e);
         }
       }
@@ -155,6 +158,12 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void conv_igemm_kernel(const ConvAr
 #pragma unroll
     for (int ps = 0; ps < APASS; ++ps) {
       float4 v = ra[ps];
+      if constexpr (!VEC4) {
+        if (p.x_u8) {
+          v.x = p.in_lut[lut_c[0] + (int)v.x]; v.y = p.in_lut[lut_c[1] + (int)v.y];
+          v.z = p.in_lut[lut_c[2] + (int)v.z]; v.w = p.in_lut[lut_c[3] + (int)v.w];
+        }
+      }
       if (has_pre) {
         v.x = v.x * psc.x + psh.x; v.y = v.y * psc.y + psh.y;
         v.z = v.z * psc.z + psh.z; v.w = v.w * psc.w + psh.w;
@@ -291,8 +300,11 @@ int launch_conv_igemm(const ConvArgs& a, int cfg, hipStream_t s) {
     return DH_EINVAL;
   if ((long long)a.N * a.H * a.W > 0x7fffffffLL || (long long)a.N * a.OH * a.OW * (a.up2 ? 4 : 1) > 0x7fffffffLL)
     return DH_EINVAL;
-  if (cfg < 0) cfg = conv_igemm_pick_cfg(a.N * a.OH * a.OW, a.Cout) + (gemm1x1_eligible(a) ? kNumCfgs : 0);
+  if (a.x_u8 && a.in_lut == nullptr) return DH_EINVAL;
+  if (cfg < 0)
+    cfg = conv_igemm_pick_cfg(a.N * a.OH * a.OW, a.Cout) + (!a.x_u8 && gemm1x1_eligible(a) ? kNumCfgs : 0);
   if (cfg >= 2 * kNumCfgs) return DH_EINVAL;
+  if (a.x_u8 && cfg >= kNumCfgs) return DH_EUNSUPPORTED;
   auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
   const int epi = (a.Cout % 4 == 0) && (a.ldy % 4 == 0) && al16(a.y) &&
                   (a.res1 == nullptr || (a.ldr1 % 4 == 0 && al16(a.res1))) &&
@@ -304,7 +316,7 @@ int launch_conv_igemm(const ConvArgs& a, int cfg, hipStream_t s) {
     return launch_gemm1x1(a, cfg, epi, s);
   }
   if (a.up2 && cfg == 0) cfg = 2;  // 128x192 + fused up-sampling epilogue exceeds the register budget
-  const bool vec4 = (a.Cin % 4 == 0) && (a.ldx % 4 == 0) && ((reinterpret_cast<uintptr_t>(a.x) & 15) == 0) &&
+  const bool vec4 = !a.x_u8 && (a.Cin % 4 == 0) && (a.ldx % 4 == 0) && ((reinterpret_cast<uintptr_t>(a.x) & 15) == 0) &&
                     (a.pre_scale == nullptr || (((reinterpret_cast<uintptr_t>(a.pre_scale) |
                                                   reinterpret_cast<uintptr_t>(a.pre_shift)) & 15) == 0));
   switch (cfg) {

@@ -424,4 +424,29 @@ int launch_zeropad(const float* x, float* y, int B, int H, int W, int C, int OH,
   return check_launch();
 }
 
+// ---- uint8 frames -> normalised fp32 (utils/transform.normalize_channels, transform.py:212-231) -------------
+namespace {
+__global__ __launch_bounds__(256) void normalize_u8_kernel(const unsigned char* __restrict__ x,
+                                                           const float* __restrict__ lut, float* __restrict__ y,
+                                                           long long total, int C) {
+  __shared__ float s_lut[4 * 256];
+  const int rows = C < 4 ? C : 4;
+  for (int i = threadIdx.x; i < rows * 256; i += blockDim.x) s_lut[i] = lut[i];
+  __syncthreads();
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+    const int c = (int)(i % C);
+    y[i] = c < 4 ? s_lut[c * 256 + x[i]] : lut[c * 256 + x[i]];
+  }
+}
+}  // namespace
+
+int launch_normalize_u8(const unsigned char* x, const float* lut, float* y, long long n_pixels, int C, hipStream_t s) {
+  if (n_pixels <= 0 || C <= 0) return DH_EINVAL;
+  const long long total = n_pixels * C;
+  const int blocks = (int)std::min<long long>((total + 255) / 256, 256 * 16);
+  normalize_u8_kernel<<<blocks, 256, 0, s>>>(x, lut, y, total, C);
+  return hipGetLastError() == hipSuccess ? DH_OK : DH_ELAUNCH;
+}
+
 }  // namespace dh

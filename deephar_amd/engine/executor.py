@@ -98,16 +98,52 @@ def grid_x(w):
     return np.linspace(0.0, 1.0, num=w).astype(np.float32)
 
 
+def normalization_lut(channels, channel_power=1):
+    """utils/transform.normalize_channels (transform.py:212-231) tabulated for every byte value, per channel:
+    the reference runs it in float32 in place (T.asarray() yields float32, transform.py:122-124), so the same
+    NumPy float32 operations on 0..255 give bit-identical values.  Returns float32 [channels, 256]."""
+    powers = [channel_power] * channels if isinstance(channel_power, int) else list(channel_power)
+    if len(powers) != channels:
+        raise ValueError('channel_power expected to be int or a list with one entry per channel')
+    lut = np.empty((channels, 256), np.float32)
+    for c, pw in enumerate(powers):
+        v = np.arange(256, dtype=np.float32)
+        v /= 255.
+        if pw != 1:
+            v = np.power(v, pw)
+        v -= .5
+        v *= 2.
+        lut[c] = v
+    return lut
+
+
 def grid_depth(d):
     """layers.py:141-143: linspace(1/(2D), 1-1/(2D), D) stored in float32 Conv1D weights."""
     s = 1 / (2 * d)
     return np.linspace(s, 1 - s, num=d).astype(np.float32)
 
 
+class _InputStep:
+    """Pseudo-step for the stand-alone uint8 normalisation launch (first on stream 0, nothing to wait for)."""
+    kind, name, stream, wait, record, deps, params = 'normalize_u8', 'input', 0, (), False, (), {}
+
+    def __init__(self, v):
+        self.outs = {'y': v}
+        self.ins = {}
+        self.attrs = {}
+
+    def flops(self, n):
+        return 0
+
+    def bytes(self, n):
+        v = self.outs['y']
+        return 5 * n * int(np.prod(v.shape))
+
+
 class BoundPlan:
     """A Plan with concrete device pointers for batch size n."""
 
-    def __init__(self, plan, n, store, device):
+    def __init__(self, plan, n, store, device, u8_norm=None):
         torch = _torch()
         self.plan, self.n, self.store, self.device = plan, n, store, device
         self.lib = _lib.load()
@@ -116,6 +152,25 @@ class BoundPlan:
         self.calls = []       # (fn, args tuple without stream, step)
         self._keep = []       # ctypes structs kept alive
         self.graph = None
+        # uint8 frames: every model input gets a byte staging buffer; convolutions that read an input directly
+        # normalise on load (dh_conv_args.x_u8), anything else is fed by a stand-alone normalisation launch
+        self.u8 = None
+        self.npre = 0         # launches in front of plan.steps[0] (step indices in `wait` lists are offset by it)
+        if u8_norm is not None:
+            self.u8 = {}
+            for v in plan.inputs:
+                lut = store.constant(('u8lut', v.C, repr(u8_norm)), lambda v=v: normalization_lut(v.C, u8_norm))
+                buf = torch.zeros((n,) + v.shape, dtype=torch.uint8, device=device)
+                users = [s for s in plan.steps for w in s.ins.values() if w is not None and w.buf is v.buf]
+                fused = all(s.kind == 'conv' and s.ins['x'].buf is v.buf and s.ins['x'].C == v.C and
+                            s.ins['x'].coff == v.coff and v.C % 4 != 0 and 'pre_bn' not in s.params and
+                            s.ins.get('res1') is None and s.ins.get('res2') is None for s in users)
+                self.u8[id(v.buf)] = (buf, lut, fused)
+                if not fused:
+                    self.calls.append((self.lib.dh_normalize_u8_f32,
+                                       (buf.data_ptr(), lut.data_ptr(), self.ptr(v), n * int(np.prod(v.shape[:-1])),
+                                        v.C), _InputStep(v)))
+                    self.npre += 1
         for step in plan.steps:
             self._bind(step)
 
@@ -168,6 +223,9 @@ class BoundPlan:
             if r2 is not None:
                 args.res2, args.ldr2 = P(r2), r2.ld
             args.pre_relu, args.post_relu, args.up2 = a['pre_relu'], a['post_relu'], a['up2']
+            if self.u8 is not None and id(x.buf) in self.u8 and self.u8[id(x.buf)][2]:
+                buf, lut, _ = self.u8[id(x.buf)]
+                args.x, args.in_lut, args.x_u8 = buf.data_ptr(), lut.data_ptr(), 1
             self._keep.append(args)
             self.calls.append((lib.dh_conv2d_f32, (C.byref(args), a.get('tile_cfg', -1)), s))
         elif k == 'dwconv':
@@ -316,13 +374,17 @@ class BoundPlan:
             return
         side = self._side_streams()
         ptrs = [stream_ptr] + [st for st in side]
+        for fn, args, step in self.calls[:self.npre]:          # input staging runs before the fork
+            _lib.check(fn(*args, stream_ptr), step.kind)
         _lib.check(lib.dh_event_record(self._fork, stream_ptr), 'fork')
         for st in side:
             _lib.check(lib.dh_stream_wait_event(st, self._fork), 'fork wait')
         for i, (fn, args, step) in enumerate(self.calls):
+            if i < self.npre:
+                continue
             sp = ptrs[step.stream]
             for w in step.wait:
-                _lib.check(lib.dh_stream_wait_event(sp, self._events[w]), 'dependency wait')
+                _lib.check(lib.dh_stream_wait_event(sp, self._events[w + self.npre]), 'dependency wait')
             rc = fn(*args, sp)
             if rc != 0:
                 _lib.check(rc, 'step %s (%s)' % (step.kind, step.name))
@@ -367,7 +429,7 @@ class BoundPlan:
         for i, (fn, args, step) in enumerate(self.calls):
             if step.kind != 'conv':
                 continue
-            sig = (self.n,) + self._conv_signature(step)
+            sig = (self.n,) + self._conv_signature(step) + ((('u8',) if args[0]._obj.x_u8 else ()))
             if sig not in table:
                 best, best_ms = -1, float('inf')
                 for cfg in range(ncfg):
@@ -444,15 +506,18 @@ class Executor:
     def stream_ptr(self):
         return self.stream.cuda_stream
 
-    def bind(self, n):
-        bp = self.bound.get(n)
+    def bind(self, n, u8_norm=None):
+        """u8_norm: None for float inputs; a channel_power (1 or a per-channel list) when the inputs are raw uint8
+        frames to be normalised on the GPU like utils/transform.normalize_channels."""
+        key = n if u8_norm is None else (n, repr(u8_norm))
+        bp = self.bound.get(key)
         if bp is None:
             torch = _torch()
             with torch.cuda.device(self.device), torch.cuda.stream(self.stream):
-                bp = BoundPlan(self.plan, n, self.store, self.device)
+                bp = BoundPlan(self.plan, n, self.store, self.device, u8_norm=u8_norm)
                 if self.autotune:
                     bp.autotune(self.stream_ptr, self.tune_table)
-            self.bound[n] = bp
+            self.bound[key] = bp
         return bp
 
     def refresh_weights(self):
@@ -468,9 +533,18 @@ class Executor:
         self.stream.synchronize()
 
     def set_inputs(self, bp, arrays):
-        """Copy host (or device) arrays [m<=n, ...] into the input buffers (fp32)."""
+        """Copy host (or device) arrays [m<=n, ...] into the input buffers (fp32, or the byte staging buffers of
+        a uint8-bound plan)."""
         torch = _torch()
         for v, arr in zip(self.plan.inputs, arrays):
+            if bp.u8 is not None:
+                dst = bp.u8[id(v.buf)][0]
+                src = torch.from_numpy(np.ascontiguousarray(arr)) if isinstance(arr, np.ndarray) else arr
+                if src.dtype != torch.uint8 or tuple(src.shape[1:]) != tuple(dst.shape[1:]) or src.shape[0] > bp.n:
+                    raise ValueError('uint8-bound plan expects uint8 input [<=%d, %s], got %s %s' %
+                                     (bp.n, tuple(dst.shape[1:]), src.dtype, tuple(src.shape)))
+                dst[:src.shape[0]].copy_(src.to(self.device, non_blocking=True))
+                continue
             dst = bp.tensor(v)
             if isinstance(arr, np.ndarray):
                 src = torch.from_numpy(np.ascontiguousarray(arr))
@@ -491,13 +565,13 @@ class Executor:
         else:
             bp.launch_all(self.stream_ptr)
 
-    def run(self, arrays, n=None):
+    def run(self, arrays, n=None, u8_norm=None):
         """arrays: list of host arrays with equal leading dim m.  Returns list of np.float32 outputs."""
         torch = _torch()
         m = arrays[0].shape[0]
         n = n or m
         with torch.cuda.device(self.device), torch.cuda.stream(self.stream):
-            bp = self.bind(n)
+            bp = self.bind(n, u8_norm=u8_norm)
             self.set_inputs(bp, arrays)
             self.forward(bp)
             outs = [bp.tensor(v)[:m].contiguous().cpu() for v in self.plan.outputs]

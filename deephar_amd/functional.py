@@ -45,10 +45,18 @@ def pack_conv_weight(w_hwio, device='cuda'):
 
 def conv2d(x, w_hwio, strides=(1, 1), padding='same', pre_scale=None, pre_shift=None, pre_relu=False,
            post_scale=None, post_shift=None, post_relu=False, res1=None, res2=None, up2=False, tile_cfg=-1,
-           packed=None):
-    """Fused conv (see dh_conv2d_f32).  x [N,H,W,Cin]; w_hwio numpy [kh,kw,Cin,Cout]."""
+           packed=None, in_lut=None):
+    """Fused conv (see dh_conv2d_f32).  x [N,H,W,Cin]; w_hwio numpy [kh,kw,Cin,Cout].  A uint8 `x` needs
+    `in_lut` (float32 [Cin,256] device tensor, engine.executor.normalization_lut): bytes are normalised on load."""
     torch = _t()
-    _chk(x, pre_scale, pre_shift, post_scale, post_shift, res1, res2)
+    if x.dtype == torch.uint8:
+        if in_lut is None or tuple(in_lut.shape) != (x.shape[-1], 256):
+            raise ValueError('uint8 input needs in_lut of shape [Cin, 256]')
+        if not x.is_cuda or not x.is_contiguous():
+            raise ValueError('conv2d expects contiguous CUDA tensors')
+        _chk(in_lut, pre_scale, pre_shift, post_scale, post_shift, res1, res2)
+    else:
+        _chk(x, pre_scale, pre_shift, post_scale, post_shift, res1, res2)
     lib = _lib.load()
     kh, kw, cin, cout = w_hwio.shape
     n, h, w_, c = x.shape
@@ -73,7 +81,21 @@ def conv2d(x, w_hwio, strides=(1, 1), padding='same', pre_scale=None, pre_shift=
     a.ldr1 = res1.shape[-1] if res1 is not None else 0
     a.ldr2 = res2.shape[-1] if res2 is not None else 0
     a.pre_relu, a.post_relu, a.up2 = int(pre_relu), int(post_relu), int(up2)
+    if x.dtype == torch.uint8:
+        a.in_lut, a.x_u8 = _p(in_lut), 1
     _lib.check(lib.dh_conv2d_f32(C.byref(a), tile_cfg, _stream()), 'dh_conv2d_f32')
+    return y
+
+
+def normalize_u8(x, lut):
+    """uint8 [.., C] -> float32 through lut [C,256] (dh_normalize_u8_f32)."""
+    torch = _t()
+    if x.dtype != torch.uint8 or not x.is_cuda or not x.is_contiguous():
+        raise ValueError('normalize_u8 expects a contiguous CUDA uint8 tensor')
+    _chk(lut)
+    y = torch.empty(x.shape, dtype=torch.float32, device=x.device)
+    _lib.check(_lib.load().dh_normalize_u8_f32(_p(x), _p(lut), _p(y), x.numel() // x.shape[-1], x.shape[-1],
+                                               _stream()), 'dh_normalize_u8_f32')
     return y
 
 

@@ -38,6 +38,9 @@ class Model:
         # independent branches run on parallel hipGraph branches (engine/schedule.py); >2 streams crashes
         # hipStreamEndCapture in ROCm 7.2's runtime on this graph shape, so 2 is the default and the cap
         self.num_streams = min(2, int(__import__('os').environ.get('DEEPHAR_STREAMS', '2')))
+        # uint8 inputs are raw frames: predict() normalises them on the GPU exactly like the reference's loaders do
+        # on the host (utils/transform.normalize_channels(frame, channel_power), transform.py:212-231)
+        self.channel_power = 1
         # validates connectivity early (raises like Keras' "graph disconnected")
         self._nodes = G.topo_nodes(self.outputs)
         reach = {t.uid for t in self.inputs}
@@ -177,7 +180,9 @@ class Model:
 
     def predict(self, x, batch_size=32, verbose=0):
         """Forward pass on the GPU in chunks of `batch_size` (keras Model.predict semantics): returns one
-        np.float32 array per model output, or a bare array when the model has a single output."""
+        np.float32 array per model output, or a bare array when the model has a single output.
+        uint8 arrays are taken as raw frames: 4x fewer bytes cross PCIe and the /255, -0.5, x2 normalisation of the
+        reference's data loaders is applied inside the first convolution (`self.channel_power` as in DataConfig)."""
         xs = list(x) if isinstance(x, (list, tuple)) else [x]
         if len(xs) != len(self.inputs):
             raise ValueError('model %s expects %d input arrays, got %d' % (self.name, len(self.inputs), len(xs)))
@@ -186,12 +191,16 @@ class Model:
         for a, t in zip(xs, self.inputs):
             if tuple(a.shape[1:]) != t.shape or a.shape[0] != total:
                 raise ValueError('input array has shape %s, model expects (N,)+%s' % (a.shape, t.shape))
+        raw = [a.dtype == np.uint8 for a in xs]
+        if any(raw) and not all(raw):
+            raise ValueError('either all inputs are uint8 frames or none is')
+        u8_norm = self.channel_power if all(raw) and raw else None
         ex = self.executor
         bs = int(min(batch_size or total, total)) if total else 1
         chunks = []
         for i in range(0, total, bs):
             part = [a[i:i + bs] for a in xs]
-            chunks.append(ex.run(part, n=bs))
+            chunks.append(ex.run(part, n=bs, u8_norm=u8_norm))
             if verbose:
                 print('%d/%d' % (min(i + bs, total), total))
         if not chunks:

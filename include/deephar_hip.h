@@ -56,6 +56,7 @@ typedef struct dh_conv_args {
   const float* post_shift;
   const float* res1;
   const float* res2;
+  const float* in_lut; /* x_u8 only: [Cin][256] value of every byte after the loader's normalisation */
   int32_t N, H, W, Cin, ldx;
   int32_t OH, OW, Cout, ldy;
   int32_t KH, KW, SH, SW, PT, PL;
@@ -64,6 +65,10 @@ typedef struct dh_conv_args {
   int32_t ldr1, ldr2;
   int32_t pre_relu, post_relu;
   int32_t up2;
+  int32_t x_u8; /* 1: x points to uint8 frames [N,H,W,ldx]; every byte goes through in_lut before the (optional)
+                   BN prologue, zero padding is applied after it.  This is utils/transform.normalize_channels
+                   (transform.py:212-231: /255, power, -0.5, *2 in float32) fused into the first convolution; only
+                   the general K x K path takes it (Cin % 4 != 0 or tile_cfg < dh_conv2d_num_tile_cfgs()/2) */
 } dh_conv_args;
 
 /* padded dims of the packed weight for a [KH,KW,Cin,Cout] (Keras HWIO) kernel */
@@ -75,6 +80,10 @@ int dh_conv2d_pack_weights_host(const float* w_hwio_host, float* packed_host, in
 int dh_conv2d_num_tile_cfgs(void);
 int dh_conv2d_pick_tile_cfg(int M, int Cout);
 int dh_conv2d_f32(const dh_conv_args* a, int tile_cfg, void* stream);
+
+/* Stand-alone version of the same normalisation for inputs that do not feed a convolution directly:
+ * y[i, c] = lut[c*256 + x[i, c]] for n_pixels x C bytes (transform.py:212-231). */
+int dh_normalize_u8_f32(const uint8_t* x, const float* lut, float* y, int64_t n_pixels, int C, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------
  * Depthwise KxK conv, stride 1, explicit padding: the depthwise half of keras SeparableConv2D

@@ -63,6 +63,11 @@ def main():
     g['norm_in'] = frame.copy()
     g['norm_out'] = transform.normalize_channels(frame.copy())
     g['norm_out_pow'] = transform.normalize_channels(frame.copy(), channel_power=(1, 2, 0.5))
+    # every byte value through the loader path: T.asarray() hands normalize_channels a float32 array
+    # (transform.py:122-124), so the whole normalisation runs in float32
+    ramp = np.repeat(np.arange(256, dtype=np.float32)[:, None, None], 3, axis=2)
+    g['norm_lut'] = transform.normalize_channels(ramp.copy())[:, 0, :].T.copy()
+    g['norm_lut_pow'] = transform.normalize_channels(ramp.copy(), channel_power=(1, 2, 0.5))[:, 0, :].T.copy()
 
     th = 0.3
     R = np.array([[np.cos(th), 0, np.sin(th)], [0, 1, 0], [-np.sin(th), 0, np.cos(th)]])

@@ -72,3 +72,13 @@ def test_pose_layout_tables():
         assert (lay.num_joints, lay.dim) == (int(ref[0]), int(ref[1]))
         assert list(lay.map_hflip) == [int(v) for v in ref[2:]]
     assert (utils.ntu25j3d.num_joints, utils.ntu25j3d.dim) == tuple(int(v) for v in G['pose_ntu25j3d'])
+
+
+def test_uint8_normalisation_table_is_the_loaders_arithmetic():
+    """engine.executor.normalization_lut (what the first convolution applies to raw uint8 frames) against the
+    reference's normalize_channels run on float32 frames holding every byte value (transform.py:122-124,212-231)."""
+    from deephar_amd.engine.executor import normalization_lut
+    assert G['norm_lut'].dtype == np.float32 and G['norm_lut'].shape == (3, 256)
+    assert np.array_equal(normalization_lut(3), G['norm_lut'])
+    assert np.array_equal(normalization_lut(3, (1, 2, 0.5)), G['norm_lut_pow'])
+    assert normalization_lut(3)[0, 0] == -1.0 and normalization_lut(3)[0, 255] == 1.0

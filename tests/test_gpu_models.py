@@ -301,3 +301,26 @@ def test_hip_matches_reference_code_goldens(tag, hip_lib, cuda):
             _check('%s.maps%d' % (tag, k), h, a, b, 2e-5, rel=True)
         else:
             _check('%s.out%d' % (tag, k), h, a, b, PX_TOL if b.shape[-1] != 1 else 1e-5, rel=(b.shape[-1] == 1))
+
+
+@pytest.mark.parametrize('tag', ['rec2d', 'merge2d', 'spnet2d'])
+def test_uint8_frames_equal_host_normalised_frames(tag, hip_lib, cuda):
+    """Model.predict on raw uint8 frames (normalisation fused into the first convolution, 4x fewer input bytes)
+    is bit-identical to predict on frames normalised on the host the way the reference's loaders do."""
+    import sys, os
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from refgolden import build_case
+    from deephar_amd.utils.transform import normalize_channels
+    m, x, _ = build_case(tag)
+    rng = np.random.default_rng(5)
+    frames = rng.integers(0, 256, x.shape, dtype=np.uint8)
+    host = normalize_channels(frames.astype(np.float32))            # float32 in, float32 arithmetic (transform.py:122)
+    assert host.dtype == np.float32
+    a = m.predict(frames, batch_size=len(frames))
+    b = m.predict(host, batch_size=len(frames))
+    a, b = (a if isinstance(a, list) else [a]), (b if isinstance(b, list) else [b])
+    for u, v in zip(a, b):
+        assert np.array_equal(u, v)
+    bp = m.executor.bound[(len(frames), repr(1))]
+    assert bp.npre == 0 and any(getattr(c[1][0], '_obj', None) is not None and c[1][0]._obj.x_u8 for c in bp.calls
+                                if c[2].kind == 'conv')               # really the fused path, not the fallback

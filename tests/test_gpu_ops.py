@@ -274,3 +274,34 @@ def test_kronecker_and_action_top(hip_lib, cuda):
     _close(F.global_maxmin_softmax(torch.from_numpy(a).to(cuda)), ref, atol=1e-8, rtol=1e-5, what='action_top')
     ref = O.global_max_min_pooling(torch.from_numpy(a))
     assert torch.equal(F.global_maxmin_softmax(torch.from_numpy(a).to(cuda), softmax=False).cpu(), ref)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('k,s,cout,power', [(3, 2, 32, 1), (7, 2, 64, 1), (3, 1, 16, (1, 2, 0.5))])
+def test_conv2d_uint8_frames_normalised_on_load(k, s, cout, power, hip_lib, cuda):
+    """dh_conv_args.x_u8: the first convolution reads raw uint8 frames and applies the loader's normalisation
+    (transform.py:212-231) per byte -- bit-identical to normalising first and convolving the fp32 frames, and
+    to the stand-alone dh_normalize_u8_f32."""
+    from deephar_amd import functional as F
+    from deephar_amd.engine.executor import normalization_lut
+    rng = np.random.default_rng(k * 10 + s)
+    frames = rng.integers(0, 256, (3, 37, 41, 3), dtype=np.uint8)
+    frames[0, :2] = 0
+    frames[1, -2:] = 255
+    w = _rand(rng, (k, k, 3, cout), 0.3)
+    lut_h = normalization_lut(3, power)
+    lut = torch.from_numpy(lut_h).cuda()
+    xb = torch.from_numpy(frames).cuda()
+    xf = F.normalize_u8(xb, lut)
+    ref = lut_h[np.arange(3)[None, None, None, :], frames]
+    assert np.array_equal(xf.cpu().numpy(), ref)
+    post = torch.from_numpy(_rand(rng, (cout,), 1.0)).cuda()
+    for cfg in (-1, 3, 6, 8):
+        y8 = F.conv2d(xb, w, strides=(s, s), in_lut=lut, post_scale=post, post_shift=post, post_relu=True, tile_cfg=cfg)
+        yf = F.conv2d(xf, w, strides=(s, s), post_scale=post, post_shift=post, post_relu=True, tile_cfg=cfg)
+        assert torch.equal(y8, yf), cfg
+    want = O.conv2d(torch.from_numpy(ref.astype(np.float64)), torch.from_numpy(w.astype(np.float64)), (s, s), 'same')
+    got = F.conv2d(xb, w, strides=(s, s), in_lut=lut)
+    _close(got, want, 2e-5, what='u8 conv vs fp64 oracle')
+    with pytest.raises(Exception):
+        F.conv2d(xb, w, strides=(s, s), in_lut=lut, tile_cfg=hip_lib.dh_conv2d_num_tile_cfgs() - 1)   # DMA GEMM: no u8
