@@ -84,6 +84,9 @@ def main():
     ap.add_argument('--dump-steps', default=None, help='write the per-kernel profile (JSON) to this path')
     ap.add_argument('--streams', type=int, default=None,
                     help='HIP streams for independent model branches (default: the engine default)')
+    ap.add_argument('--input', choices=('f32', 'u8'), default='f32',
+                    help="f32: normalised float frames resident in HBM (what the reference's predict() is handed); "
+                         "u8: raw uint8 frames resident in HBM, normalised inside the first convolution")
     ap.add_argument('--tune-cache', default=None,
                     help='JSON file with the autotuned conv tilings: loaded if present (no tuning launches, '
                          'keeps rocprofv3 kernel stats clean), written otherwise')
@@ -120,11 +123,15 @@ def main():
     if args.tune_cache and os.path.exists(args.tune_cache):
         with open(args.tune_cache) as f:
             ex.tune_table = {tuple(json.loads(k)): v for k, v in json.load(f).items()}
-    bp = ex.bind(n)
+    u8 = args.input == 'u8'
+    bp = ex.bind(n, u8_norm=1 if u8 else None)
     if args.tune_cache and rank == 0 and not os.path.exists(args.tune_cache):
         with open(args.tune_cache, 'w') as f:
             json.dump({json.dumps(list(k)): v for k, v in ex.tune_table.items()}, f)
-    x = np.random.default_rng(1234 + rank).uniform(-1, 1, (n, 256, 256, 3)).astype(np.float32)
+    if u8:
+        x = np.random.default_rng(1234 + rank).integers(0, 256, (n, 256, 256, 3), dtype=np.uint8)
+    else:
+        x = np.random.default_rng(1234 + rank).uniform(-1, 1, (n, 256, 256, 3)).astype(np.float32)
     with torch.cuda.stream(ex.stream):
         ex.set_inputs(bp, [x])           # inputs resident in HBM before the timed region
     ex.stream.synchronize()
@@ -133,7 +140,8 @@ def main():
         # the input buffer is re-used by later activations inside one forward, so every step re-stages the
         # frames from a second HBM-resident copy (device-to-device, inside the timed region)
         with torch.cuda.stream(ex.stream):
-            bp.tensor(plan.inputs[0]).copy_(x_dev, non_blocking=True)
+            if not u8:        # (the uint8 staging buffer lives outside the arena and is never overwritten)
+                bp.tensor(plan.inputs[0]).copy_(x_dev, non_blocking=True)
             ex.forward(bp)
 
     with torch.cuda.stream(ex.stream):
@@ -163,7 +171,8 @@ def main():
 
     # ---- per-kernel pass (HIP events on the launch stream) ----------------------------------------------
     with torch.cuda.stream(ex.stream):
-        bp.tensor(plan.inputs[0]).copy_(x_dev)
+        if not u8:
+            bp.tensor(plan.inputs[0]).copy_(x_dev)
         times_ms = bp.profile(ex.stream_ptr, reps=3)
     kinds = {}
     for s, ms in zip(plan.steps, times_ms):
@@ -220,7 +229,7 @@ def main():
             'config': {'workload': 'MPII single-person 256x256, ReceptionNet %d blocks J=16 ctx=2 k=5, pose-only '
                                    'forward, batch=%d per GPU (BASELINE.json configs[1])' % (args.blocks, n),
                        'global_batch': world * n, 'parallelism': 'frame-shard x%d (no collective)' % world,
-                       'hipgraph': not args.no_graph, 'streams': plan.nstreams, 'outputs_finite_in_range': ok},
+                       'hipgraph': not args.no_graph, 'streams': plan.nstreams, 'input': args.input, 'outputs_finite_in_range': ok},
             'roofline': {'bound': 'mfma', 'kernel': dom_name,
                          'achieved': round(achieved, 2), 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
                          'frac': round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), 'traffic': None,

@@ -105,11 +105,12 @@ def load():
         import torch  # noqa: F401
     except ImportError:
         pass
-    if not os.path.exists(LIB_PATH):
+    path = os.environ.get('DEEPHAR_HIP_LIB', LIB_PATH)     # override: A/B runs of two builds of the library
+    if not os.path.exists(path):
         raise DeepharHipError(
             'libdeephar_hip.so not found at %s -- the HIP back-end is mandatory (no CPU fallback). '
-            'Build it with `python -m deephar_amd.csrc.build`.' % LIB_PATH)
-    lib = C.CDLL(LIB_PATH)
+            'Build it with `python -m deephar_amd.csrc.build`.' % path)
+    lib = C.CDLL(path)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)   # AttributeError if the .so does not export a declared symbol
         fn.restype = res

@@ -18,71 +18,169 @@ __device__ __forceinline__ int xcd_tile(int b, int nwg) {
 // Each wave stages one 32 x (TN*32) row block through its private LDS slab and reads it back row-wise, so
 // the BN affine / residual loads / stores are 16-byte wide and whole output rows are contiguous.
 //   out = relu?( acc*post_scale + post_shift + res1[m] + res2[mo] ), optionally written 2x up-sampled.
-template <int WM, int WN, int TM, int TN, bool UP2>
+//
+// The epilogue is latency-, not bandwidth-bound: a work-group that loads its residual tile only after the last
+// MFMA sits through one HBM round trip per dependent batch while the other work-groups of the CU -- started
+// together, same amount of work -- sit in the same phase, so nothing fills the matrix pipe.  Hence:
+//   * EpiPrefetch::issue() puts ALL residual (res1) loads of the tile in flight (registers) and is called by the
+//     K loop one step before its end, so the round trip overlaps the last MFMA block;
+//   * the row loop is fully unrolled, branch-free (clamped addresses, predicated stores): every remaining load
+//     of a row block is issued before the first use;
+//   * only the first LDS staging needs a work-group barrier (the stage buffers are being re-used); the slab is
+//     wave-private after that.
+template <int TM, int TN>
+struct EpiPrefetch {
+  static constexpr int ROW4 = TN * 8;      // float4 per staged row
+  static constexpr int IT = 4 * TN;        // row-loop iterations per 32-row block (32*ROW4 / 64 lanes)
+  // holding a whole residual tile costs 4*IT*TM VGPRs across the last K-step: only the one-row-block tilings
+  // (128x32 .. 128x96 per work-group) have them to spare
+  static constexpr bool kEnabled = (TM == 1);
+  float4 r1[kEnabled ? TM : 1][kEnabled ? IT : 1];
+
+  template <int WM, int WN>
+  __device__ __forceinline__ void issue(const ConvArgs& p, int m0, int n0, int M, int epi_vec) {
+    if constexpr (kEnabled) {
+      if (epi_vec == 0 || p.res1 == nullptr) return;
+      const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+      const int wm = wave / WN, wn = wave % WN;
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int it = 0; it < IT; ++it) {
+          const int f = lane + 64 * it;
+          const int row = f / ROW4, c4 = f - row * ROW4;
+          int m = m0 + (wm * TM + i) * 32 + row;
+          int n = n0 + wn * TN * 32 + c4 * 4;
+          m = m < M ? m : M - 1;
+          n = n < p.Cout ? n : p.Cout - 4;
+          r1[i][it] = *reinterpret_cast<const float4*>(p.res1 + (size_t)m * p.ldr1 + n);
+        }
+    }
+  }
+};
+
+// PRE: the caller issued EpiPrefetch::issue() (and the tiling holds a prefetched tile)
+template <int WM, int WN, int TM, int TN, bool UP2, bool PRE>
 __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x16 (&acc)[TM][TN], float* smem, int m0,
-                                              int n0, int M, int epi_vec) {
+                                              int n0, int M, int epi_vec, const EpiPrefetch<TM, TN>& pre) {
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;
   const int wm = wave / WN, wn = wave % WN;
   const int li = lane & 31, lh = lane >> 5;
   constexpr int LDC = TN * 32 + 4;
-  constexpr int ROW4 = TN * 8;                 // float4 per staged row
+  constexpr int ROW4 = TN * 8;
+  constexpr int IT = 4 * TN;
+  constexpr int NSC = (64 % ROW4 == 0) ? 1 : 3;   // distinct column groups a lane meets over the row loop
+  constexpr bool kPre = PRE && EpiPrefetch<TM, TN>::kEnabled;
   float* sC = smem + wave * 32 * LDC;
   const int ohw = p.OH * p.OW;
   const bool vec = epi_vec != 0;
+  __syncthreads();                            // every wave is done with the operand stages
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
-    __syncthreads();
+    if (i > 0) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // slab reads of the previous block
 #pragma unroll
     for (int j = 0; j < TN; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r)
         sC[((r & 3) + 8 * (r >> 2) + 4 * lh) * LDC + j * 32 + li] = acc[i][j][r];
-    __syncthreads();
-#pragma unroll 2
-    for (int f = lane; f < 32 * ROW4; f += 64) {
-      const int row = f / ROW4, c4 = f - row * ROW4;
-      const int m = m0 + (wm * TM + i) * 32 + row;
-      const int n = n0 + wn * TN * 32 + c4 * 4;
-      if (m >= M || n >= p.Cout) continue;
-      float4 v = *reinterpret_cast<const float4*>(&sC[row * LDC + c4 * 4]);
-      size_t mo[4];
-      int nout = 1;
-      if constexpr (UP2) {
-        const int fr = m / ohw;
-        const int rem = m - fr * ohw;
-        const int oh = rem / p.OW, ow = rem - oh * p.OW;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                // wave-private slab: no barrier needed
+    if (vec) {
+      // pass 1: every load of this row block that is not in flight already
+      float4 rr[kPre ? 1 : IT], sc[NSC], sh[NSC];
+      int ncol[NSC];
 #pragma unroll
-        for (int d = 0; d < 4; ++d)
-          mo[d] = ((size_t)fr * 2 * p.OH + 2 * oh + (d >> 1)) * (2 * p.OW) + 2 * ow + (d & 1);
-        nout = 4;
-      } else {
-        mo[0] = (size_t)m;
-      }
-      if (vec) {
+      for (int q = 0; q < NSC; ++q) {
+        const int c4 = (lane + 64 * q) % ROW4;
+        const int n = n0 + wn * TN * 32 + c4 * 4;
+        ncol[q] = n < p.Cout ? n : p.Cout - 4;
         if (p.post_scale != nullptr) {
-          const float4 sc = *reinterpret_cast<const float4*>(p.post_scale + n);
-          const float4 sh = *reinterpret_cast<const float4*>(p.post_shift + n);
-          v.x = v.x * sc.x + sh.x; v.y = v.y * sc.y + sh.y; v.z = v.z * sc.z + sh.z; v.w = v.w * sc.w + sh.w;
+          sc[q] = *reinterpret_cast<const float4*>(p.post_scale + ncol[q]);
+          sh[q] = *reinterpret_cast<const float4*>(p.post_shift + ncol[q]);
+        }
+      }
+      if constexpr (!kPre) {
+        if (p.res1 != nullptr) {
+#pragma unroll
+          for (int it = 0; it < IT; ++it) {
+            const int row = (lane + 64 * it) / ROW4;
+            const int m = m0 + (wm * TM + i) * 32 + row;
+            rr[it] = *reinterpret_cast<const float4*>(p.res1 + (size_t)(m < M ? m : M - 1) * p.ldr1 + ncol[it % NSC]);
+          }
+        }
+      }
+      // pass 2: combine + store
+#pragma unroll
+      for (int it = 0; it < IT; ++it) {
+        const int f = lane + 64 * it;
+        const int row = f / ROW4, c4 = f - row * ROW4;
+        const int m = m0 + (wm * TM + i) * 32 + row;
+        const int nc = ncol[it % NSC];
+        const bool ok = m < M && n0 + wn * TN * 32 + c4 * 4 < p.Cout;
+        const size_t mc = (size_t)(m < M ? m : M - 1);
+        float4 t = *reinterpret_cast<const float4*>(&sC[row * LDC + c4 * 4]);
+        if (p.post_scale != nullptr) {
+          const float4 a = sc[it % NSC], b = sh[it % NSC];
+          t.x = t.x * a.x + b.x; t.y = t.y * a.y + b.y; t.z = t.z * a.z + b.z; t.w = t.w * a.w + b.w;
         }
         if (p.res1 != nullptr) {
-          const float4 r = *reinterpret_cast<const float4*>(p.res1 + (size_t)m * p.ldr1 + n);
-          v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
+          float4 r;
+          if constexpr (kPre) r = pre.r1[i][it]; else r = rr[it];
+          t.x += r.x; t.y += r.y; t.z += r.z; t.w += r.w;
         }
+        if constexpr (UP2) {
+          const int fr = (int)mc / ohw;
+          const int rem = (int)mc - fr * ohw;
+          const int oh = rem / p.OW, ow = rem - oh * p.OW;
+          float4 r2[4];
+          size_t mo[4];
 #pragma unroll
-        for (int d = 0; d < (UP2 ? 4 : 1); ++d) {
-          float4 o = v;
+          for (int d = 0; d < 4; ++d) {
+            mo[d] = ((size_t)fr * 2 * p.OH + 2 * oh + (d >> 1)) * (2 * p.OW) + 2 * ow + (d & 1);
+            if (p.res2 != nullptr) r2[d] = *reinterpret_cast<const float4*>(p.res2 + mo[d] * p.ldr2 + nc);
+          }
+#pragma unroll
+          for (int d = 0; d < 4; ++d) {
+            float4 o = t;
+            if (p.res2 != nullptr) { o.x += r2[d].x; o.y += r2[d].y; o.z += r2[d].z; o.w += r2[d].w; }
+            if (p.post_relu) {
+              o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f);
+            }
+            if (ok) *reinterpret_cast<float4*>(p.y + mo[d] * p.ldy + nc) = o;
+          }
+        } else {
+          float4 o = t;
           if (p.res2 != nullptr) {
-            const float4 r = *reinterpret_cast<const float4*>(p.res2 + mo[d] * p.ldr2 + n);
+            const float4 r = *reinterpret_cast<const float4*>(p.res2 + mc * p.ldr2 + nc);
             o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w;
           }
           if (p.post_relu) {
             o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f);
           }
-          *reinterpret_cast<float4*>(p.y + mo[d] * p.ldy + n) = o;
+          if (ok) *reinterpret_cast<float4*>(p.y + mc * p.ldy + nc) = o;
         }
-      } else {
+      }
+    } else {
+      for (int f = lane; f < 32 * ROW4; f += 64) {
+        const int row = f / ROW4, c4 = f - row * ROW4;
+        const int m = m0 + (wm * TM + i) * 32 + row;
+        const int n = n0 + wn * TN * 32 + c4 * 4;
+        if (m >= M || n >= p.Cout) continue;
+        const float4 v = *reinterpret_cast<const float4*>(&sC[row * LDC + c4 * 4]);
+        size_t mo[4];
+        int nout = 1;
+        if constexpr (UP2) {
+          const int fr = m / ohw;
+          const int rem = m - fr * ohw;
+          const int oh = rem / p.OW, ow = rem - oh * p.OW;
+#pragma unroll
+          for (int d = 0; d < 4; ++d)
+            mo[d] = ((size_t)fr * 2 * p.OH + 2 * oh + (d >> 1)) * (2 * p.OW) + 2 * ow + (d & 1);
+          nout = 4;
+        } else {
+          mo[0] = (size_t)m;
+        }
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           if (n + e >= p.Cout) break;

@@ -232,7 +232,8 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void conv_igemm_kernel(const ConvAr
     }
   }
 
-  conv_epilogue<WM, WN, TM, TN, UP2>(p, acc, smem, m0, n0, M, epi_vec);
+  EpiPrefetch<TM, TN> pre;   // (register-staged kernel: no spare VGPRs to hold a residual tile across the K loop)
+  conv_epilogue<WM, WN, TM, TN, UP2, false>(p, acc, smem, m0, n0, M, epi_vec, pre);
 }
 
 struct Cfg { int wm, wn, tm, tn; };

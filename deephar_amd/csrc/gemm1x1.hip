@@ -34,6 +34,7 @@ __device__ __forceinline__ float4 lds_rd(unsigned addr) {
   return v;
 }
 __device__ __forceinline__ void lgkm_wait() {
+  __builtin_amdgcn_sched_barrier(0);   // MFMAs issued before the wait stay before it: they are what hides the read
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_sched_barrier(0);
 }
@@ -162,9 +163,10 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void gemm1x1_kernel(const ConvArgs 
   // data has not reached yet.  Hence every fetch and its wait live in the straight-line body of one K-step.
   // (Fetching tile kt+1's first fragments before the loop back-edge was tried: correct with a tail wait, but
   // the loop-carried fragment registers cost more than the hidden LDS latency buys: 111 vs 118 TFLOP/s.)
+  EpiPrefetch<TM, TN> pre;
   for (int kt = 0; kt < nk; ++kt) {
     const int cur = kt & 1;
-    if (kt + 1 < nk) issue(kt + 1, cur ^ 1);          // DMA of the next tile flies during this MFMA block
+    if (kt == nk - 1) pre.template issue<WM, WN>(p, m0, n0, M, epi_vec);   // lands during the last MFMA block
     const unsigned so = (unsigned)(cur * STAGE * 4);
     unsigned a_addr[TM][4];
 #pragma unroll
@@ -173,9 +175,12 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void gemm1x1_kernel(const ConvArgs 
       for (int q = 0; q < 4; ++q) a_addr[i][q] = a_base[i][q] + so;
     const unsigned b_addr = b_base + so;
 
-    // sub-step s+1's fragments are in flight (asm ds_read) while sub-step s's MFMAs run
+    // sub-step s+1's fragments are in flight (asm ds_read) while sub-step s's MFMAs run; the first read of the
+    // K-step has no MFMAs to hide behind, so the DMA issue of the next tile (address VALU + 6 loads) goes there
     float4 fa0[TM], fb0[TN], fa1[TM], fb1[TN];
     fetch_frags<TM, TN, BN, BOFF, 0>(a_addr, b_addr, fa0, fb0);
+    __builtin_amdgcn_sched_barrier(0);
+    if (kt + 1 < nk) issue(kt + 1, cur ^ 1);          // DMA of the next tile flies during this MFMA block
     lgkm_wait();
     fetch_frags<TM, TN, BN, BOFF, 1>(a_addr, b_addr, fa1, fb1);
     __builtin_amdgcn_sched_barrier(0);   // keep the reads ahead of the MFMAs they overlap with
@@ -200,7 +205,7 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void gemm1x1_kernel(const ConvArgs 
     __syncthreads();
   }
 
-  conv_epilogue<WM, WN, TM, TN, UP2>(p, acc, smem, m0, n0, M, epi_vec);
+  conv_epilogue<WM, WN, TM, TN, UP2, true>(p, acc, smem, m0, n0, M, epi_vec, pre);
 }
 
 template <int WM, int WN, int TM, int TN, bool UP2, bool RELU>

@@ -20,14 +20,32 @@ def test_capi_exports_every_declared_symbol(hip_lib):
     assert hip_lib.dh_error_string(-2).decode().startswith('configuration')
 
 
-def test_ctypes_structs_match_header_layout(hip_lib):
-    """Field order/size of the ctypes mirrors vs the C structs (9 pointers + 23 ints etc.)."""
+def test_ctypes_structs_match_header_layout(hip_lib, tmp_path):
+    """Size and every field offset of the ctypes mirrors against what a C compiler makes of include/deephar_hip.h."""
+    import re
+    import subprocess
     from deephar_amd import _lib
-    assert ctypes.sizeof(_lib.ConvArgs) == 9 * 8 + 23 * 4 + 4      # padded to 8
-    assert ctypes.sizeof(_lib.DwArgs) == 5 * 8 + 11 * 4 + 4
-    assert ctypes.sizeof(_lib.PoolArgs) == 2 * 8 + 15 * 4 + 4
-    assert ctypes.sizeof(_lib.EltArgs) == 6 * 8 + 4 * 4 + 8 + 4 * 4
-    assert ctypes.sizeof(_lib.SamArgs) == 8 * 8 + 9 * 4 + 2 * 4 + 4
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    header = open(os.path.join(root, 'include', 'deephar_hip.h')).read()
+    pairs = {'dh_conv_args': _lib.ConvArgs, 'dh_dw_args': _lib.DwArgs, 'dh_pool_args': _lib.PoolArgs,
+             'dh_elt_args': _lib.EltArgs, 'dh_sam_args': _lib.SamArgs}
+    structs = set(re.findall(r'typedef struct (dh_\w+_args)', header))
+    assert structs == set(pairs), structs ^ set(pairs)
+    lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "deephar_hip.h"', 'int main(void) {']
+    for cname, ct in pairs.items():
+        lines.append('printf("%s %%zu\\n", sizeof(%s));' % (cname, cname))
+        for fname, _ in ct._fields_:
+            lines.append('printf("%s.%s %%zu\\n", offsetof(%s, %s));' % (cname, fname, cname, fname))
+    lines.append('return 0; }')
+    src = tmp_path / 'layout.c'
+    src.write_text('\n'.join(lines))
+    exe = str(tmp_path / 'layout')
+    subprocess.run(['gcc', '-I', os.path.join(root, 'include'), str(src), '-o', exe], check=True)
+    got = dict(l.split() for l in subprocess.run([exe], capture_output=True, text=True, check=True).stdout.splitlines())
+    for cname, ct in pairs.items():
+        assert int(got[cname]) == ctypes.sizeof(ct), cname
+        for fname, _ in ct._fields_:
+            assert int(got['%s.%s' % (cname, fname)]) == getattr(ct, fname).offset, (cname, fname)
 
 
 def test_weight_packing_roundtrip_and_layout(hip_lib):
