@@ -11,57 +11,121 @@
 namespace dh {
 namespace {
 
-constexpr int CG = 16;             // channels per workgroup
+constexpr int CG = 16;             // channels per workgroup (depth_from_maps; soft-argmax when there is enough work)
 constexpr int NTH = 256;           // threads per workgroup
-constexpr int PL = NTH / CG;       // pixel lanes per workgroup (16)
 constexpr int NW = NTH / 64;       // waves
 
-// Reduce across the lanes of a wave that share the same (tid % CG): xor 16 and 32.
-__device__ __forceinline__ float wave_max_cg(float v) {
-  v = fmaxf(v, __shfl_xor(v, 16));
-  v = fmaxf(v, __shfl_xor(v, 32));
+// Reduce across the lanes of a wave that share the same (tid % G): xor G, 2G, .. 32.
+template <int G>
+__device__ __forceinline__ float wave_max_g(float v) {
+#pragma unroll
+  for (int d = G; d < 64; d <<= 1) v = fmaxf(v, __shfl_xor(v, d));
   return v;
 }
-__device__ __forceinline__ float wave_sum_cg(float v) {
-  v += __shfl_xor(v, 16);
-  v += __shfl_xor(v, 32);
+template <int G>
+__device__ __forceinline__ float wave_sum_g(float v) {
+#pragma unroll
+  for (int d = G; d < 64; d <<= 1) v += __shfl_xor(v, d);
   return v;
 }
+__device__ __forceinline__ float wave_max_cg(float v) { return wave_max_g<CG>(v); }
+__device__ __forceinline__ float wave_sum_cg(float v) { return wave_sum_g<CG>(v); }
+constexpr int PL = NTH / CG;       // pixel lanes per workgroup at CG channels (16)
 
-// One workgroup = (frame f, group of CG channels).  Two passes over the (L2-resident) maps:
+// One workgroup = (frame f, group of CG channels).  Two passes over the group's maps:
 //   pass 1: max of alpha*h (soft-max shift) and max 2x2-window sum of the raw map (confidence)
 //   pass 2: e = exp(alpha*h - max); sums of e, e*gx, e*gy; max 2x2-window sum of e; optional prob store
+// STAGED: the H*W*CG slab is first copied to LDS with every load in flight at once (one HBM/L2 round trip
+// instead of one per loop iteration -- the kernel is latency-, not bandwidth-bound) and both passes read LDS.
+// Thread mapping and summation order are identical in both variants, so are the results.
+// G channels per work-group: 16 when F*C/16 work-groups already fill the chip, 4 otherwise (the kernel is
+// issue-bound inside a work-group, so at small batch x channels the idle CUs are the resource to use).
+template <int G, bool STAGED>
 __global__ __launch_bounds__(NTH) void softargmax2d_kernel(const SamArgs p) {
+  constexpr int CG = G;
+  constexpr int PL = NTH / G;
   __shared__ float red[7][NW][CG];
+  extern __shared__ __attribute__((aligned(16))) float slab[];   // STAGED: [H*W][CG], then gx[W], gy[H]
   const int tid = threadIdx.x;
   const int cc = tid % CG, pl = tid / CG;
   const int wave = tid >> 6;
   const int groups = (p.C + CG - 1) / CG;
   const int f = blockIdx.x / groups;
-  const int c = (blockIdx.x % groups) * CG + cc;
+  const int c0 = (blockIdx.x % groups) * CG;
+  const int c = c0 + cc;
   const bool cok = c < p.C;
   const int HW = p.H * p.W;
   const float* base = p.h + (size_t)f * HW * p.ldh + c;
 
+  float* sgx = slab + HW * CG;
+  float* sgy = sgx + p.W;
+  if constexpr (STAGED) {
+    const float* src = p.h + (size_t)f * HW * p.ldh + c0;
+    const bool vec = (p.ldh % 4 == 0) && (c0 + CG <= p.C) && ((reinterpret_cast<uintptr_t>(src) & 15) == 0);
+    if (vec) {
+      // 8 independent 16-byte loads in flight per thread and round
+      const int total = HW * (CG / 4);
+      for (int i0 = tid; i0 < total; i0 += 8 * NTH) {
+        float4 t[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          int i = i0 + k * NTH;
+          i = i < total ? i : total - 1;
+          const int px = i / (CG / 4), q4 = i - px * (CG / 4);
+          t[k] = *reinterpret_cast<const float4*>(src + (size_t)px * p.ldh + q4 * 4);
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          const int i = i0 + k * NTH;
+          if (i < total) *reinterpret_cast<float4*>(&slab[i * 4]) = t[k];      // slab index = px*CG + q4*4 = i*4
+        }
+      }
+    } else {
+      const int total = HW * CG;
+      for (int i0 = tid; i0 < total; i0 += 8 * NTH) {
+        float t[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          int i = i0 + k * NTH;
+          i = i < total ? i : total - 1;
+          const int px = i / CG, ch = i - px * CG;
+          t[k] = src[(size_t)px * p.ldh + (c0 + ch < p.C ? ch : p.C - 1 - c0)];
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          const int i = i0 + k * NTH;
+          if (i < total) slab[i] = t[k];
+        }
+      }
+    }
+    // the coordinate grids are read once per pixel in pass 2: keep them next to the maps
+    for (int i = tid; i < p.W; i += NTH) sgx[i] = p.gx[i];
+    for (int i = tid; i < p.H; i += NTH) sgy[i] = p.gy[i];
+    __syncthreads();
+  }
+  auto at = [&](int px) -> float {
+    if constexpr (STAGED) return slab[px * CG + cc];
+    else return base[(size_t)px * p.ldh];
+  };
+
   float vmax = -INFINITY, cmax = -INFINITY, rmax = -INFINITY;
   if (cok) {
     for (int px = pl; px < HW; px += PL) {
-      const float v = base[(size_t)px * p.ldh];
+      const float v = at(px);
       vmax = fmaxf(vmax, p.alpha * v);
       rmax = fmaxf(rmax, v);
       if (p.conf_raw != nullptr) {
         const int r = px / p.W, q = px - r * p.W;
         if (r + 1 < p.H && q + 1 < p.W) {
-          const float s4 = ((v + base[(size_t)(px + 1) * p.ldh]) + base[(size_t)(px + p.W) * p.ldh]) +
-                           base[(size_t)(px + p.W + 1) * p.ldh];
+          const float s4 = ((v + at(px + 1)) + at(px + p.W)) + at(px + p.W + 1);
           cmax = fmaxf(cmax, p.conf_scale * s4);
         }
       }
     }
   }
-  vmax = wave_max_cg(vmax);
-  cmax = wave_max_cg(cmax);
-  rmax = wave_max_cg(rmax);
+  vmax = wave_max_g<G>(vmax);
+  cmax = wave_max_g<G>(cmax);
+  rmax = wave_max_g<G>(rmax);
   if ((tid & 63) < CG) { red[0][wave][cc] = vmax; red[1][wave][cc] = cmax; red[6][wave][cc] = rmax; }
   __syncthreads();
   vmax = red[0][0][cc]; cmax = red[1][0][cc]; rmax = red[6][0][cc];
@@ -75,19 +139,19 @@ __global__ __launch_bounds__(NTH) void softargmax2d_kernel(const SamArgs p) {
   if (cok) {
     for (int px = pl; px < HW; px += PL) {
       const int r = px / p.W, q = px - r * p.W;
-      const float e = expf(p.alpha * base[(size_t)px * p.ldh] - vmax);
+      const float e = expf(p.alpha * at(px) - vmax);
       s += e;
-      sx = fmaf(e, p.gx[q], sx);
-      sy = fmaf(e, p.gy[r], sy);
+      sx = fmaf(e, STAGED ? sgx[q] : p.gx[q], sx);
+      sy = fmaf(e, STAGED ? sgy[r] : p.gy[r], sy);
       if (p.conf_prob != nullptr && r + 1 < p.H && q + 1 < p.W) {
-        const float e1 = expf(p.alpha * base[(size_t)(px + 1) * p.ldh] - vmax);
-        const float e2 = expf(p.alpha * base[(size_t)(px + p.W) * p.ldh] - vmax);
-        const float e3 = expf(p.alpha * base[(size_t)(px + p.W + 1) * p.ldh] - vmax);
+        const float e1 = expf(p.alpha * at(px + 1) - vmax);
+        const float e2 = expf(p.alpha * at(px + p.W) - vmax);
+        const float e3 = expf(p.alpha * at(px + p.W + 1) - vmax);
         pmax = fmaxf(pmax, ((e + e1) + e2) + e3);
       }
     }
   }
-  s = wave_sum_cg(s); sx = wave_sum_cg(sx); sy = wave_sum_cg(sy); pmax = wave_max_cg(pmax);
+  s = wave_sum_g<G>(s); sx = wave_sum_g<G>(sx); sy = wave_sum_g<G>(sy); pmax = wave_max_g<G>(pmax);
   if ((tid & 63) < CG) {
     red[2][wave][cc] = s; red[3][wave][cc] = sx; red[4][wave][cc] = sy; red[5][wave][cc] = pmax;
   }
@@ -112,8 +176,7 @@ __global__ __launch_bounds__(NTH) void softargmax2d_kernel(const SamArgs p) {
   }
   if (p.prob != nullptr && cok) {
     float* pb = p.prob + (size_t)f * HW * p.ldp + c;
-    for (int px = pl; px < HW; px += PL)
-      pb[(size_t)px * p.ldp] = expf(p.alpha * base[(size_t)px * p.ldh] - vmax) * inv;
+    for (int px = pl; px < HW; px += PL) pb[(size_t)px * p.ldp] = expf(p.alpha * at(px) - vmax) * inv;
   }
 }
 
@@ -310,9 +373,25 @@ __global__ __launch_bounds__(256) void global_maxmin_softmax_kernel(const float*
 int launch_softargmax2d(const SamArgs& a, hipStream_t s) {
   if (a.F <= 0 || a.C <= 0 || a.H <= 0 || a.W <= 0 || a.h == nullptr || a.gx == nullptr || a.gy == nullptr)
     return DH_EINVAL;
-  const long long blocks = (long long)a.F * ((a.C + CG - 1) / CG);
-  if (blocks > 0x7fffffffLL) return DH_EINVAL;
-  hipLaunchKernelGGL(softargmax2d_kernel, dim3((unsigned)blocks), dim3(NTH), 0, s, a);
+  const long long blocks16 = (long long)a.F * ((a.C + 15) / 16);
+  const long long blocks4 = (long long)a.F * ((a.C + 3) / 4);
+  if (blocks4 > 0x7fffffffLL) return DH_EINVAL;
+  constexpr size_t kMaxSlab = 128 * 1024;     // 32x32x16 maps need 64 KB: above the default dynamic-LDS limit
+  static bool once = (hipFuncSetAttribute((const void*)softargmax2d_kernel<16, true>,
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxSlab), true);
+  (void)once;
+  const bool wide = blocks16 >= 1024;
+  const int g = wide ? 16 : 4;
+  const size_t slab = ((size_t)a.H * a.W * g + a.W + a.H) * sizeof(float);
+  const dim3 grid((unsigned)(wide ? blocks16 : blocks4));
+  if (slab > (wide ? kMaxSlab : (size_t)60 * 1024)) {
+    if (wide) hipLaunchKernelGGL((softargmax2d_kernel<16, false>), grid, dim3(NTH), 0, s, a);
+    else hipLaunchKernelGGL((softargmax2d_kernel<4, false>), grid, dim3(NTH), 0, s, a);
+  } else if (wide) {
+    hipLaunchKernelGGL((softargmax2d_kernel<16, true>), grid, dim3(NTH), slab, s, a);
+  } else {
+    hipLaunchKernelGGL((softargmax2d_kernel<4, true>), grid, dim3(NTH), slab, s, a);
+  }
   return check_launch();
 }
 
