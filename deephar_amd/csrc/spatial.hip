@@ -102,10 +102,9 @@ __global__ __launch_bounds__(256) void dwconv_lds_kernel(const DwArgs p, const i
   const int ctiles = (p.W + tw - 1) / tw;
   int b = blockIdx.x;
   const int cchunk = b % chunks; b /= chunks;
-  const int ct = b % ctiles; b /= ctiles;
-  const int band = b % bands;
-  const int n = b / bands;
-  const int c0 = cchunk * 32, r0 = band * rows, w0 = ct * tw;
+  const int ct = b % ctiles;
+  const int n = b / ctiles;
+  const int c0 = cchunk * 32, w0 = ct * tw;
   const int th = rows + KS - 1, twh = tw + KS - 1;
   float4* tile = dsm;                               // [th][twh][DW_PITCH]
   float4* wts = dsm + th * twh * DW_PITCH;          // [KS*KS][DW_CQ]
@@ -118,62 +117,75 @@ __global__ __launch_bounds__(256) void dwconv_lds_kernel(const DwArgs p, const i
   float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = zero;
   if (aff) { sc = ld4(p.pre_scale + c0 + q_in * 4); sh = ld4(p.pre_shift + c0 + q_in * 4); }
   const int npix = th * twh;
-  // all global loads of the tile are issued back to back (clamped addresses), then masked and stored:
-  // one HBM round trip per workgroup instead of one per loop iteration
+  // One work-group walks down the bands of its (frame, column tile, 32-channel chunk).  All global loads of a
+  // band's halo tile are issued back to back (clamped addresses) into registers -- one HBM round trip per band,
+  // not one per loop iteration -- and the loads of band t+1 are in flight while band t is computed from LDS.
   constexpr int MAXL = 14;                          // ceil(12*36*8 / 256)
   float4 stage[MAXL];
   unsigned okmask = 0;
+  auto fetch = [&](int band) {
+    const int r0 = band * rows;
+    okmask = 0;
 #pragma unroll
-  for (int j = 0; j < MAXL; ++j) {                  // (tid + j*256) % 8 == tid % 8: the quad is fixed per thread
-    const int px = (tid + j * 256) / DW_CQ;
-    const int tr = px / twh, tc = px - tr * twh;
-    const int ih = r0 - p.PT + tr, iw = w0 - p.PL + tc;
-    const bool ok = px < npix && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
-    const size_t off = ok ? ((size_t)(n * p.H + ih) * p.W + iw) * p.ldx + c0 + q_in * 4 : 0;
-    stage[j] = ld4(p.x + off);
-    okmask |= (ok ? 1u : 0u) << j;
-  }
-#pragma unroll
-  for (int j = 0; j < MAXL; ++j) {
-    const int px = (tid + j * 256) / DW_CQ;
-    if (px >= npix) continue;
-    float4 v = stage[j];
-    if (aff) v = fma4(v, sc, sh);
-    if (p.pre_relu) v = max4(v, zero);
-    if (!((okmask >> j) & 1u)) v = zero;
-    tile[px * DW_PITCH + q_in] = v;
-  }
-  __syncthreads();
-
+    for (int j = 0; j < MAXL; ++j) {                // (tid + j*256) % 8 == tid % 8: the quad is fixed per thread
+      const int px = (tid + j * 256) / DW_CQ;
+      const int tr = px / twh, tc = px - tr * twh;
+      const int ih = r0 - p.PT + tr, iw = w0 - p.PL + tc;
+      const bool ok = px < npix && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
+      const size_t off = ok ? ((size_t)(n * p.H + ih) * p.W + iw) * p.ldx + c0 + q_in * 4 : 0;
+      stage[j] = ld4(p.x + off);
+      okmask |= (ok ? 1u : 0u) << j;
+    }
+  };
   const int strips = tw >> 3;
   const int q = tid & (DW_CQ - 1);
   const int strip = (tid >> 3) % strips;
   const int row = (tid >> 3) / strips;
-  if (row >= rows || r0 + row >= p.H) return;
-  float4 acc[8];
+
+  fetch(0);
+  for (int band = 0; band < bands; ++band) {
+    const int r0 = band * rows;
 #pragma unroll
-  for (int i = 0; i < 8; ++i) acc[i] = zero;
-#pragma unroll
-  for (int kh = 0; kh < KS; ++kh) {
-    float4 wv[KS];
-#pragma unroll
-    for (int kw = 0; kw < KS; ++kw) wv[kw] = wts[(kh * KS + kw) * DW_CQ + q];
-    const float4* src = tile + ((row + kh) * twh + strip * 8) * DW_PITCH + q;
-#pragma unroll
-    for (int j = 0; j < 8 + KS - 1; ++j) {
-      const float4 v = src[j * DW_PITCH];
-#pragma unroll
-      for (int kw = 0; kw < KS; ++kw) {
-        const int o = j - kw;
-        if (o >= 0 && o < 8) acc[o] = fma4(v, wv[kw], acc[o]);
-      }
+    for (int j = 0; j < MAXL; ++j) {
+      const int px = (tid + j * 256) / DW_CQ;
+      if (px >= npix) continue;
+      float4 v = stage[j];
+      if (aff) v = fma4(v, sc, sh);
+      if (p.pre_relu) v = max4(v, zero);
+      if (!((okmask >> j) & 1u)) v = zero;
+      tile[px * DW_PITCH + q_in] = v;
     }
-  }
-  const int ow0 = w0 + strip * 8;
-  float* out = p.y + ((size_t)(n * p.H + r0 + row) * p.W + ow0) * p.ldy + c0 + q * 4;
+    __syncthreads();
+    if (band + 1 < bands) fetch(band + 1);
+
+    if (row < rows && r0 + row < p.H) {
+      float4 acc[8];
 #pragma unroll
-  for (int i = 0; i < 8; ++i)
-    if (ow0 + i < p.W) st4(out + (size_t)i * p.ldy, acc[i]);
+      for (int i = 0; i < 8; ++i) acc[i] = zero;
+#pragma unroll 1                                   // one kernel row of LDS reads in flight: keeps 2+ waves per SIMD
+      for (int kh = 0; kh < KS; ++kh) {
+        float4 wv[KS];
+#pragma unroll
+        for (int kw = 0; kw < KS; ++kw) wv[kw] = wts[(kh * KS + kw) * DW_CQ + q];
+        const float4* src = tile + ((row + kh) * twh + strip * 8) * DW_PITCH + q;
+#pragma unroll
+        for (int j = 0; j < 8 + KS - 1; ++j) {
+          const float4 v = src[j * DW_PITCH];
+#pragma unroll
+          for (int kw = 0; kw < KS; ++kw) {
+            const int o = j - kw;
+            if (o >= 0 && o < 8) acc[o] = fma4(v, wv[kw], acc[o]);
+          }
+        }
+      }
+      const int ow0 = w0 + strip * 8;
+      float* out = p.y + ((size_t)(n * p.H + r0 + row) * p.W + ow0) * p.ldy + c0 + q * 4;
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+        if (ow0 + i < p.W) st4(out + (size_t)i * p.ldy, acc[i]);
+    }
+    __syncthreads();                                // every wave is done reading the tile before it is refilled
+  }
 }
 
 // Generic fallback (any KW, C not a multiple of 4): one thread per output element.
@@ -350,7 +362,7 @@ int launch_dwconv(const DwArgs& a, hipStream_t s) {
     const int tw = a.W >= 32 ? 32 : a.W;
     int rows = 256 / (8 * (tw / 8));
     if (rows > a.H) rows = a.H;
-    const long long blocks = (long long)a.N * ((a.H + rows - 1) / rows) * ((a.W + tw - 1) / tw) * (a.C / 32);
+    const long long blocks = (long long)a.N * ((a.W + tw - 1) / tw) * (a.C / 32);    // bands are walked inside
     const size_t lds = ((size_t)(rows + a.KW - 1) * (tw + a.KW - 1) * DW_PITCH + (size_t)a.KW * a.KW * DW_CQ) * 16;
     if (blocks <= 0x7fffffffLL && lds <= 64 * 1024 &&
         (rows + a.KW - 1) * (tw + a.KW - 1) * DW_CQ <= 14 * 256) {
