@@ -91,6 +91,9 @@ __global__ __launch_bounds__(256) void dwconv_kernel(const DwArgs p) {
 // filter taps of the chunk sit in LDS too.  Thread = (channel quad, 8-column strip, row).
 // ------------------------------------------------------------------------------------------------
 constexpr int DW_CQ = 8;        // channel quads per workgroup (32 channels)
+#ifndef DW_LDS_MIN_W
+#define DW_LDS_MIN_W 16
+#endif
 constexpr int DW_PITCH = 9;     // float4 per tile pixel (8 + 1 pad: spreads strips over LDS banks)
 
 template <int KS>
@@ -357,7 +360,7 @@ int launch_dwconv(const DwArgs& a, hipStream_t s) {
   if (a.N <= 0 || a.C <= 0 || a.KH <= 0 || a.KW <= 0) return DH_EINVAL;
   const bool vec = (a.C % 4 == 0) && (a.ldx % 4 == 0) && (a.ldy % 4 == 0) && al16(a.x) && al16(a.y) &&
                    al16(a.w) && (a.pre_scale == nullptr || (al16(a.pre_scale) && al16(a.pre_shift)));
-  if (vec && a.KH == a.KW && (a.KW == 5 || a.KW == 3) && a.C % 32 == 0 && a.W >= 32 && a.W % 8 == 0) {   // measured: pays from 32-wide maps up
+  if (vec && a.KH == a.KW && (a.KW == 5 || a.KW == 3) && a.C % 32 == 0 && a.W >= DW_LDS_MIN_W && a.W % 8 == 0) {
     // LDS-tiled path: column tile = min(W, 32), 8-column strips, rows chosen to fill 256 threads
     const int tw = a.W >= 32 ? 32 : a.W;
     int rows = 256 / (8 * (tw / 8));
