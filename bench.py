@@ -211,6 +211,17 @@ def main():
     dom_name, dom = max(by_kernel.items(), key=lambda kv: kv[1]['ms'])
     achieved = dom['flops'] / (dom['ms'] * 1e-3) / 1e12
 
+    # HBM traffic of the dominant kernel: PMC counters cannot be read from inside this process; the per-launch
+    # figure comes from the separate rocprofv3 --pmc passes recorded under profiles/ (same kernel, same shape)
+    traffic, traffic_src = None, None
+    pmc_path = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'pmc_dominant_kernel.json')
+    if os.path.exists(pmc_path) and dom_name.startswith('gemm1x1_kernel') and n == 64 and \
+            abs(dom['flops'] / dom['launches'] / 1e9 - 43.49) < 0.01:
+        with open(pmc_path) as f:
+            pmc = json.load(f)
+        traffic = pmc['fetch_bytes_per_launch'] + pmc['write_bytes_per_launch']
+        traffic_src = pmc['source']
+
     if rank == 0:
         value = world * n * args.steps / dt
         out = {
@@ -232,7 +243,9 @@ def main():
                        'hipgraph': not args.no_graph, 'streams': plan.nstreams, 'input': args.input, 'outputs_finite_in_range': ok},
             'roofline': {'bound': 'mfma', 'kernel': dom_name,
                          'achieved': round(achieved, 2), 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
-                         'frac': round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), 'traffic': None,
+                         'frac': round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), 'traffic': traffic,
+                         'traffic_unit': 'bytes/launch (HBM read + write, PMC)', 'traffic_source': traffic_src,
+                         'algorithmic_bytes_per_launch': 454e6 if traffic else None,
                          'launches_per_step': dom['launches'],
                          'avg_launch_us': round(1e3 * dom['ms'] / dom['launches'], 2),
                          'gflop_per_launch': round(dom['flops'] / dom['launches'] / 1e9, 2),
