@@ -195,8 +195,11 @@ class Model:
         if any(raw) and not all(raw):
             raise ValueError('either all inputs are uint8 frames or none is')
         u8_norm = self.channel_power if all(raw) and raw else None
+        if total == 0:                       # nothing to run (and nothing that needs the GPU)
+            outs = [np.zeros((0,) + t.shape, np.float32) for t in self.outputs]
+            return outs[0] if len(outs) == 1 else outs
         ex = self.executor
-        bs = int(min(batch_size or total, total)) if total else 1
+        bs = int(min(batch_size or total, total))
         chunks = []
         for i in range(0, total, bs):
             part = [a[i:i + bs] for a in xs]

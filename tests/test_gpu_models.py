@@ -324,3 +324,22 @@ def test_uint8_frames_equal_host_normalised_frames(tag, hip_lib, cuda):
     bp = m.executor.bound[(len(frames), repr(1))]
     assert bp.npre == 0 and any(getattr(c[1][0], '_obj', None) is not None and c[1][0]._obj.x_u8 for c in bp.calls
                                 if c[2].kind == 'conv')               # really the fused path, not the fallback
+
+
+def test_ragged_batches_and_chunking(hip_lib, cuda):
+    """keras predict semantics: any number of frames, any batch_size (last chunk short), one frame; results do
+    not depend on how the frames were chunked (bit-exact)."""
+    import sys, os
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from refgolden import build_case
+    m, x, _ = build_case('rec2d')
+    rng = np.random.default_rng(3)
+    x = rng.uniform(-1, 1, (5,) + x.shape[1:]).astype(np.float32)
+    ref = m.predict(x, batch_size=5)
+    for bs in (1, 2, 3, 4, 64):
+        got = m.predict(x, batch_size=bs)
+        for a, b in zip(ref, got):
+            assert np.array_equal(a, b), bs
+    one = m.predict(x[3:4])
+    for a, b in zip(ref, one):
+        assert np.array_equal(a[3:4], b)

@@ -240,3 +240,18 @@ def test_no_cpu_execution_path():
     src = ''.join(open(os.path.join(os.path.dirname(deephar_amd.__file__), f)).read()
                   for f in ('model.py', 'engine/executor.py', 'engine/planner.py', 'functional.py', 'layers.py'))
     assert 'import oracle' not in src and 'from oracle' not in src
+
+
+def test_predict_validates_inputs_without_a_gpu():
+    """Shape / count / dtype errors and the empty batch are host logic: no device is touched."""
+    from deephar_amd.models import reception
+    m = reception.build((64, 64, 3), 16, dim=2, num_context_per_joint=2, num_blocks=1, ksize=(3, 3))
+    out = m.predict(np.zeros((0, 64, 64, 3), np.float32))
+    assert out.shape == (0, 16, 3) and out.dtype == np.float32        # single output: a bare array, like Keras
+    m2 = reception.build((64, 64, 3), 16, dim=2, num_context_per_joint=2, num_blocks=2, ksize=(3, 3),
+                         concat_pose_confidence=False)
+    assert [o.shape for o in m2.predict(np.zeros((0, 64, 64, 3), np.uint8))] == [(0, 16, 2), (0, 16, 1)] * 2
+    with pytest.raises(ValueError):
+        m.predict(np.zeros((2, 32, 32, 3), np.float32))
+    with pytest.raises(ValueError):
+        m.predict([np.zeros((2, 64, 64, 3), np.float32)] * 2)
