@@ -6,6 +6,7 @@ torch compute and no CPU fallback.  The launch sequence of a bound plan is captu
 (dh_graph_*), so steady-state `predict` costs one graph launch per batch instead of ~300 kernel launches.
 """
 import ctypes as C
+import os
 
 import numpy as np
 
@@ -450,7 +451,10 @@ class BoundPlan:
         lib.dh_event_destroy(e0)
         lib.dh_event_destroy(e1)
         if self.graph is not None:
-            lib.dh_graph_destroy(self.graph)
+            if self.plan.nstreams > 1:
+                _GRAPH_GRAVEYARD.append(self.graph)      # see __del__
+            else:
+                lib.dh_graph_destroy(self.graph)
             self.graph = None
         return table
 
@@ -478,11 +482,23 @@ class BoundPlan:
         return times / reps
 
     def __del__(self):
+        # ROCm 7.2: hipGraphExecDestroy of a graph captured across several streams (event fork/join nodes) leaves
+        # the runtime in a state where a LATER capture + launch of another multi-stream graph segfaults
+        # (tools/repro_seg.py: two bound plans of one model destroyed, next model's first replay crashes; the
+        # same sequence with one stream, or without the destroy, is fine).  Multi-stream graph execs are therefore
+        # parked until process exit instead of destroyed -- a few KB of kernel-node parameters each.
         try:
             if self.graph is not None:
-                self.lib.dh_graph_destroy(self.graph)
+                if self.plan.nstreams > 1:
+                    _GRAPH_GRAVEYARD.append(self.graph)
+                else:
+                    self.lib.dh_graph_destroy(self.graph)
+                self.graph = None
         except Exception:
             pass
+
+
+_GRAPH_GRAVEYARD = []
 
 
 class Executor:
