@@ -24,6 +24,8 @@ import time
 
 import numpy as np
 
+os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')   # RCCL across processes needs dmabuf IPC on this driver
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
