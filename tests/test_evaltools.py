@@ -134,3 +134,54 @@ def test_bbox_from_predicted_poses():
             return {'frame': fval[i], 'afmat': A[i], 'seq_idx': 4, 'frame_list': [10 + i]}
     out = predict_frame_bboxes(model, DS(), 0)
     assert sorted(out) == ['4.10', '4.11', '4.12'] and all(len(v) == 4 and isinstance(v[0], int) for v in out.values())
+
+
+@pytest.mark.skipif(not os.path.isdir('/root/reference/exp/common'), reason='needs the reference checkout')
+def test_reference_harness_runs_unmodified_on_the_compat_modules():
+    """deephar_amd.compat.install(): the reference's OWN exp/common/mpii_tools.py and h36m_tools.py, loaded as they
+    are, resolve `deephar.*` / `keras.*` to this package and reproduce their golden numbers -- i.e. measures,
+    transform, camera, bbox and the printing helpers are drop-ins for what the harness star-imports."""
+    import contextlib
+    import importlib.util
+    import io
+    import deephar_amd.compat as compat
+    assert 'keras' not in sys.modules and 'deephar' not in sys.modules
+    names = compat.install()
+    try:
+        assert 'deephar.models.reception' in names and 'keras.models' in names
+        from deephar.models import reception, split_model          # noqa: F401  (what the eval scripts import)
+        from deephar.config import ModelConfig, mpii_sp_dataconf    # noqa: F401
+        from keras.models import Model
+        from keras.layers import concatenate
+        import deephar_amd
+        assert Model is deephar_amd.Model and concatenate is deephar_amd.concatenate
+        assert mpii_sp_dataconf.input_shape == (256, 256, 3)
+        import deephar.data
+        with pytest.raises(NotImplementedError):
+            deephar.data.MpiiSinglePerson('datasets/MPII')
+
+        def load(name):
+            spec = importlib.util.spec_from_file_location('refexp_' + name, '/root/reference/exp/common/%s.py' % name)
+            mod = importlib.util.module_from_spec(spec)
+            spec.loader.exec_module(mod)
+            return mod
+        mpii, h36 = load('mpii_tools'), load('h36m_tools')
+        sys.modules['deephar.data.human36m'] = type(sys)('deephar.data.human36m')
+        sys.modules['deephar.data.human36m'].ACTION_LABELS = ['act%d' % i for i in range(16)]
+        fval, pval, A, head = G['mpii_fval'], G['mpii_pval'], G['mpii_A'], G['mpii_head']
+        with contextlib.redirect_stdout(io.StringIO()):
+            s = mpii.eval_singleperson_pckh(S.StubModel((8, 8, 3), [('pose', 16, 3)] * 4), fval, pval, A, head,
+                                            refp=2.0, verbose=0)
+            e = h36.eval_human36m_sc_error(S.StubModel((8, 8, 3), [('pose', 17, 4)] * 3), G['h36_x'], G['h36_pw'],
+                                           G['h36_A'].copy(), G['h36_rootz'], G['h36_scam'], G['h36_action'])
+        np.testing.assert_allclose(s, G['mpii_pckh'], **EXACT)
+        np.testing.assert_allclose(e, G['h36_err'], rtol=1e-12)
+        ds = S.FakeBoxDataset(6, seed=1)
+        model = S.StubModel((8, 8, 3), [('pose', 16, 2)] * 3, ds=ds)
+        with contextlib.redirect_stdout(io.StringIO()):
+            outs = mpii.refine_pred(model, ds.frames(), ds.afmat(), ds.bbox(), ds, 2, 1, num_iter=3)
+        np.testing.assert_allclose(np.stack(outs), G['mpii_refine'], rtol=1e-13, atol=1e-10)
+    finally:
+        compat.uninstall()
+        sys.modules.pop('deephar.data.human36m', None)
+    assert 'keras' not in sys.modules and 'deephar' not in sys.modules
