@@ -623,12 +623,13 @@ class _Writer:
         return self.put(struct.pack('<BBHII4x', 1, 0, len(msgs), 1, len(body)) + body)
 
     def dataset(self, arr):
-        a = np.ascontiguousarray(arr)
+        a = np.asarray(arr)
+        shape = a.shape                       # (np.ascontiguousarray would turn a scalar into shape (1,))
         if a.dtype.byteorder == '>':
             a = a.astype(a.dtype.newbyteorder('<'))
-        raw = a.tobytes()
+        raw = a.tobytes()                     # C order
         daddr = self.put(raw) if raw else UNDEF
-        msgs = [_msg(0x01, _space_msg(a.shape)), _msg(0x03, _dtype_msg(a.dtype)),
+        msgs = [_msg(0x01, _space_msg(shape)), _msg(0x03, _dtype_msg(a.dtype)),
                 _msg(0x05, struct.pack('<BBBB', 2, 2, 2, 0)),
                 _msg(0x08, struct.pack('<BBQQ', 3, 1, daddr, len(raw)))]
         return self.header(msgs)

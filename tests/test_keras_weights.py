@@ -163,3 +163,77 @@ def test_nested_model_lists_trainables_before_statistics():
     first_stat = roles.index('moving_mean')
     assert all(r in ('moving_mean', 'moving_variance') for r in roles[first_stat:])
     assert all(r in ('kernel', 'beta', 'depthwise_kernel', 'pointwise_kernel') for r in roles[:first_stat])
+
+
+def test_hdf5_round_trip_fuzz(tmp_path):
+    """Random trees (nesting, many members, odd names, float32/float64/int32, empty and scalar datasets, string and
+    numeric attributes) written by deephar_amd.hdf5 read back identically; with h5py around, libhdf5 agrees."""
+    from hypothesis import given, settings, strategies as st, HealthCheck
+    names = st.text(alphabet='abcXYZ019_:.-', min_size=1, max_size=12)
+    dtypes = st.sampled_from([np.float32, np.float64, np.int32])
+    shapes = st.lists(st.integers(0, 5), min_size=0, max_size=4).map(tuple)
+
+    @st.composite
+    def arrays(draw):
+        dt, shp = draw(dtypes), draw(shapes)
+        n = int(np.prod(shp)) if shp else 1
+        vals = draw(st.lists(st.integers(-1000, 1000), min_size=n, max_size=n))
+        return np.array(vals, dtype=dt).reshape(shp)
+
+    @st.composite
+    def trees(draw, depth=0):
+        t = {}
+        for k in draw(st.lists(names, min_size=0, max_size=6, unique=True)):
+            if depth < 2 and draw(st.booleans()):
+                t[k] = draw(trees(depth + 1))
+            else:
+                t[k] = draw(arrays())
+        if draw(st.booleans()):
+            t[hdf5.ATTRS] = {'weight_names': [n.encode() for n in draw(st.lists(names, max_size=5))],
+                             'scalar': np.float32(draw(st.integers(-5, 5))), 'tag': draw(names).encode()}
+        return t
+
+    def check(node, tree):
+        keys = sorted(k for k in tree if k != hdf5.ATTRS)
+        assert sorted(node.keys()) == keys
+        if hdf5.ATTRS in tree:
+            at = tree[hdf5.ATTRS]
+            assert [w for w in np.atleast_1d(node.attrs['weight_names'])] == at['weight_names'] or \
+                (len(at['weight_names']) == 0 and len(node.attrs['weight_names']) == 0)
+            assert float(node.attrs['scalar']) == float(at['scalar']) and node.attrs['tag'] == at['tag']
+        for k in keys:
+            if isinstance(tree[k], dict):
+                check(node[k], tree[k])
+            else:
+                got = np.asarray(node[k])
+                assert got.dtype == tree[k].dtype and got.shape == tree[k].shape and np.array_equal(got, tree[k])
+
+    counter = [0]
+
+    @settings(max_examples=60, deadline=None, suppress_health_check=list(HealthCheck))
+    @given(trees())
+    def run(tree):
+        counter[0] += 1
+        p = str(tmp_path / ('f%d.h5' % counter[0]))
+        hdf5.write_file(p, tree)
+        check(hdf5.File(p), tree)
+    run()
+    assert counter[0] >= 30
+
+
+@pytest.mark.skipif(not os.path.exists('/opt/conda/bin/python3.9'), reason='no interpreter with h5py')
+def test_libhdf5_reads_odd_datasets_we_write(tmp_path):
+    """Scalar, empty, int and float64 datasets, nested groups with odd names, string-list / scalar attributes."""
+    tree = {hdf5.ATTRS: {'layer_names': [b'g:0', b'h.1'], 'n': np.int32(3), 'tag': b'x'},
+            'g:0': {'s': np.float32(2.5), 'e': np.zeros((0, 4), np.float32), 'i': np.arange(6, dtype=np.int32).reshape(2, 3),
+                    hdf5.ATTRS: {'weight_names': [b's', b'e', b'i']}},
+            'h.1': {'deep': {'er': {'d': np.linspace(0, 1, 7)}}, hdf5.ATTRS: {'weight_names': []}}}
+    p = str(tmp_path / 'odd.h5')
+    hdf5.write_file(p, tree)
+    code = ("import h5py,sys,numpy as np;f=h5py.File(sys.argv[1],'r');g=f['g:0'];"
+            "print(float(g['s'][()]), g['e'].shape, g['i'][()].sum(), f['h.1/deep/er/d'][()].sum(), "
+            "[x.decode() for x in f.attrs['layer_names']], int(f.attrs['n']), len(f['h.1'].attrs['weight_names']), "
+            "[x.decode() for x in g.attrs['weight_names']])")
+    out = subprocess.run(['/opt/conda/bin/python3.9', '-c', code, p], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr
+    assert out.stdout.strip() == "2.5 (0, 4) 15 3.5 ['g:0', 'h.1'] 3 0 ['s', 'e', 'i']", out.stdout
