@@ -110,55 +110,65 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x16 (&acc)[T
           }
         }
       }
-      // pass 2: combine + store
+      // second residual (read at OUTPUT resolution): also loaded before the first store -- the compiler must
+      // assume y may alias res2 and would otherwise keep every load behind the previous iteration's store, one
+      // memory round trip per row.  Up-sampling writes (and reads) 4 positions per row: chunks of CH rows.
+      constexpr int CH = UP2 ? (IT < 4 ? IT : 4) : IT;     // rows per chunk: <= 16 float4 of res2 in flight
+      constexpr int ND = UP2 ? 4 : 1;
 #pragma unroll
-      for (int it = 0; it < IT; ++it) {
-        const int f = lane + 64 * it;
-        const int row = f / ROW4, c4 = f - row * ROW4;
-        const int m = m0 + (wm * TM + i) * 32 + row;
-        const int nc = ncol[it % NSC];
-        const bool ok = m < M && n0 + wn * TN * 32 + c4 * 4 < p.Cout;
-        const size_t mc = (size_t)(m < M ? m : M - 1);
-        float4 t = *reinterpret_cast<const float4*>(&sC[row * LDC + c4 * 4]);
-        if (p.post_scale != nullptr) {
-          const float4 a = sc[it % NSC], b = sh[it % NSC];
-          t.x = t.x * a.x + b.x; t.y = t.y * a.y + b.y; t.z = t.z * a.z + b.z; t.w = t.w * a.w + b.w;
-        }
-        if (p.res1 != nullptr) {
-          float4 r;
-          if constexpr (kPre) r = pre.r1[i][it]; else r = rr[it];
-          t.x += r.x; t.y += r.y; t.z += r.z; t.w += r.w;
-        }
-        if constexpr (UP2) {
-          const int fr = (int)mc / ohw;
-          const int rem = (int)mc - fr * ohw;
-          const int oh = rem / p.OW, ow = rem - oh * p.OW;
-          float4 r2[4];
-          size_t mo[4];
+      for (int c0 = 0; c0 < IT; c0 += CH) {
+        float4 r2[CH][ND];
+        size_t mo[CH][ND];
 #pragma unroll
-          for (int d = 0; d < 4; ++d) {
-            mo[d] = ((size_t)fr * 2 * p.OH + 2 * oh + (d >> 1)) * (2 * p.OW) + 2 * ow + (d & 1);
-            if (p.res2 != nullptr) r2[d] = *reinterpret_cast<const float4*>(p.res2 + mo[d] * p.ldr2 + nc);
+        for (int u = 0; u < CH; ++u) {
+          const int it = c0 + u;
+          const int row = (lane + 64 * it) / ROW4;
+          const int m = m0 + (wm * TM + i) * 32 + row;
+          const int mc = m < M ? m : M - 1;
+          if constexpr (UP2) {
+            const int fr = mc / ohw;
+            const int rem = mc - fr * ohw;
+            const int oh = rem / p.OW, ow = rem - oh * p.OW;
+#pragma unroll
+            for (int d = 0; d < 4; ++d)
+              mo[u][d] = ((size_t)fr * 2 * p.OH + 2 * oh + (d >> 1)) * (2 * p.OW) + 2 * ow + (d & 1);
+          } else {
+            mo[u][0] = (size_t)mc;
+          }
+          if (p.res2 != nullptr) {
+#pragma unroll
+            for (int d = 0; d < ND; ++d)
+              r2[u][d] = *reinterpret_cast<const float4*>(p.res2 + mo[u][d] * p.ldr2 + ncol[it % NSC]);
+          }
+        }
+        // combine + store
+#pragma unroll
+        for (int u = 0; u < CH; ++u) {
+          const int it = c0 + u;
+          const int f = lane + 64 * it;
+          const int row = f / ROW4, c4 = f - row * ROW4;
+          const int m = m0 + (wm * TM + i) * 32 + row;
+          const int nc = ncol[it % NSC];
+          const bool ok = m < M && n0 + wn * TN * 32 + c4 * 4 < p.Cout;
+          float4 t = *reinterpret_cast<const float4*>(&sC[row * LDC + c4 * 4]);
+          if (p.post_scale != nullptr) {
+            const float4 a = sc[it % NSC], b = sh[it % NSC];
+            t.x = t.x * a.x + b.x; t.y = t.y * a.y + b.y; t.z = t.z * a.z + b.z; t.w = t.w * a.w + b.w;
+          }
+          if (p.res1 != nullptr) {
+            float4 r;
+            if constexpr (kPre) r = pre.r1[i][it]; else r = rr[it];
+            t.x += r.x; t.y += r.y; t.z += r.z; t.w += r.w;
           }
 #pragma unroll
-          for (int d = 0; d < 4; ++d) {
+          for (int d = 0; d < ND; ++d) {
             float4 o = t;
-            if (p.res2 != nullptr) { o.x += r2[d].x; o.y += r2[d].y; o.z += r2[d].z; o.w += r2[d].w; }
+            if (p.res2 != nullptr) { o.x += r2[u][d].x; o.y += r2[u][d].y; o.z += r2[u][d].z; o.w += r2[u][d].w; }
             if (p.post_relu) {
               o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f);
             }
-            if (ok) *reinterpret_cast<float4*>(p.y + mo[d] * p.ldy + nc) = o;
+            if (ok) *reinterpret_cast<float4*>(p.y + mo[u][d] * p.ldy + nc) = o;
           }
-        } else {
-          float4 o = t;
-          if (p.res2 != nullptr) {
-            const float4 r = *reinterpret_cast<const float4*>(p.res2 + mc * p.ldr2 + nc);
-            o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w;
-          }
-          if (p.post_relu) {
-            o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f);
-          }
-          if (ok) *reinterpret_cast<float4*>(p.y + mc * p.ldy + nc) = o;
         }
       }
     } else {
