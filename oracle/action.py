@@ -1,5 +1,5 @@
 """CPU restatement of the merge action model (reference deephar/models/action.py).
-TEST INFRASTRUCTURE (see oracle/__init__.py) -- parity unpinned.
+TEST INFRASTRUCTURE (see oracle/__init__.py: graph wiring pinned by reference-code goldens, Keras/TF layer numerics restated).
 
 TimeDistributed(f)(x) is restated as "fold T into the batch, apply f, unfold" (SURVEY.md A.3).
 """

@@ -1,5 +1,5 @@
 """Op-level restatement of the reference's layer vocabulary (deephar/layers.py, deephar/activations.py)
-on PyTorch-CPU.  TEST INFRASTRUCTURE (see oracle/__init__.py) -- parity unpinned.
+on PyTorch-CPU.  TEST INFRASTRUCTURE (see oracle/__init__.py: graph wiring pinned by reference-code goldens, Keras/TF layer numerics restated).
 
 Tensors are NHWC torch tensors of the dtype chosen by the caller (float32 = the reference's dtype,
 float64 = accuracy arbiter).  Keras/TF defaults restated from SURVEY.md A.3:

@@ -1,5 +1,5 @@
 """CPU restatement of the ReceptionNet forward pass (reference deephar/models/reception.py).
-TEST INFRASTRUCTURE (see oracle/__init__.py) -- parity unpinned.
+TEST INFRASTRUCTURE (see oracle/__init__.py: graph wiring pinned by reference-code goldens, Keras/TF layer numerics restated).
 
 Written as straight functional code in the reference's source order, so that layer creation order (and with
 it the weight naming of oracle/naming.py) follows the reference.  Everything is NHWC.

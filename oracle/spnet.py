@@ -1,5 +1,5 @@
 """CPU restatement of SPNet (reference deephar/models/spnet.py + models/common.py).
-TEST INFRASTRUCTURE (see oracle/__init__.py) -- parity unpinned.
+TEST INFRASTRUCTURE (see oracle/__init__.py: graph wiring pinned by reference-code goldens, Keras/TF layer numerics restated).
 
 Frame-level tensors are kept as [N*T, H, W, C] (TimeDistributed == fold T into the batch); the action stream
 works on [N, T, J, C] planes.  Every weight-carrying layer of SPNet is explicitly named in the reference, so
