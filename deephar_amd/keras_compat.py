@@ -17,6 +17,12 @@ Keras does, so this module rebuilds, from the graph IR, what Keras would have se
     frozen layers report everything as non-trainable, in the same relative order.
 
 `layout(model)` returns the groups `save_weights` would write; `load_hdf5` / `save_hdf5` use it.
+
+Verified group-for-group against the reference's builders for the families the reference loads BY ORDER (ReceptionNet
+2-D / 3-D, merge models; 11 configurations).  SPNet is loaded by the reference with by_name=True, which only needs the
+top-level layer names and the per-layer weight order (verified); the relative ORDER of SPNet's parallel pose / action
+branches is not reproduced exactly (its fused decoder ops span several Keras layers at the top level), so an SPNet
+file written here loads in Keras with by_name=True, like the reference's own SPNet files.
 """
 import sys
 
