@@ -347,7 +347,7 @@ class BoundPlan:
         """Lazily created extra HIP streams + sync events for the parallel branches of the plan."""
         if getattr(self, '_streams', None) is None:
             lib = self.lib
-            self._streams, self._events, self._join, self._fork = [], {}, [], C.c_void_p()
+            self._streams, self._events, self._join, self._fork, self._relay = [], {}, [], C.c_void_p(), {}
             for _ in range(self.plan.nstreams - 1):
                 st, ev = C.c_void_p(), C.c_void_p()
                 _lib.check(lib.dh_stream_create(C.byref(st)), 'stream create')
@@ -385,7 +385,22 @@ class BoundPlan:
                 continue
             sp = ptrs[step.stream]
             for w in step.wait:
-                _lib.check(lib.dh_stream_wait_event(sp, self._events[w + self.npre]), 'dependency wait')
+                ev = self._events[w + self.npre]
+                src = self.calls[w + self.npre][2].stream
+                if step.stream != 0 and src > step.stream:
+                    # ROCm 7.2 stream capture segfaults (hipStreamEndCapture) once two SIDE streams have waited on
+                    # each other's events in both directions (tools/micro/capture_pattern.hip).  A lower-numbered
+                    # side stream therefore never waits on a higher-numbered one directly: the origin stream waits
+                    # and re-publishes the dependency.
+                    key = (i, w)
+                    if key not in self._relay:
+                        r = C.c_void_p()
+                        _lib.check(lib.dh_event_create_sync(C.byref(r)), 'event create')
+                        self._relay[key] = r
+                    _lib.check(lib.dh_stream_wait_event(stream_ptr, ev), 'relay wait')
+                    _lib.check(lib.dh_event_record(self._relay[key], stream_ptr), 'relay record')
+                    ev = self._relay[key]
+                _lib.check(lib.dh_stream_wait_event(sp, ev), 'dependency wait')
             rc = fn(*args, sp)
             if rc != 0:
                 _lib.check(rc, 'step %s (%s)' % (step.kind, step.name))

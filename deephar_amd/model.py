@@ -35,9 +35,9 @@ class Model:
         self.trainable = True
         self._plan = None
         self._exec = None
-        # independent branches run on parallel hipGraph branches (engine/schedule.py); >2 streams crashes
-        # hipStreamEndCapture in ROCm 7.2's runtime on this graph shape, so 2 is the default and the cap
-        self.num_streams = min(2, int(__import__('os').environ.get('DEEPHAR_STREAMS', '2')))
+        # independent branches run on parallel hipGraph branches (engine/schedule.py); measured on the MPII model:
+        # 2 streams +1..8 % over one, 3 and 4 streams 2-3 % SLOWER than 2 (chip-filling kernels only contend)
+        self.num_streams = max(1, int(__import__('os').environ.get('DEEPHAR_STREAMS', '2')))
         # uint8 inputs are raw frames: predict() normalises them on the GPU exactly like the reference's loaders do
         # on the host (utils/transform.normalize_channels(frame, channel_power), transform.py:212-231)
         self.channel_power = 1
