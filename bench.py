@@ -198,7 +198,9 @@ def main():
         t = TILES[cfg % 9]
         b = lambda v: 'true' if v else 'false'
         if cfg >= 9:
-            return 'gemm1x1_kernel<%d, %d, %d, %d, %s, %s>' % (t + (b(s.attrs['up2']), b(s.attrs['pre_relu'])))
+            a = s.attrs
+            kxk = not (a['kh'] == a['kw'] == 1 and a['sh'] == a['sw'] == 1 and a['pt'] == a['pl'] == 0)
+            return 'gemm1x1_kernel<%d, %d, %d, %d, %s, %s, %s>' % (t + (b(a['up2']), b(a['pre_relu']), b(kxk)))
         vec4 = s.ins['x'].C % 4 == 0 and s.ins['x'].ld % 4 == 0
         return 'conv_igemm_kernel<%d, %d, %d, %d, %s, %s>' % (t + (b(vec4), b(s.attrs['up2'])))
 

@@ -19,6 +19,9 @@ namespace {
 
 constexpr int BK = 32;
 
+// Source of the DMA for rows / taps that fall into the zero padding of a K x K convolution (KXK variant).
+__device__ __attribute__((aligned(128))) float g_zero_page[BK] = {};
+
 typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 
@@ -55,7 +58,10 @@ __device__ __forceinline__ void fetch_frags(const unsigned (&a_addr)[TM][4], uns
   if constexpr (TN > 2) fb[2] = lds_rd<BO + 1024>(b_addr);
 }
 
-template <int WM, int WN, int TM, int TN, bool UP2, bool RELU>
+// KXK: the same kernel as an implicit GEMM over a K x K (strided, zero-padded) convolution whose Cin is a multiple
+// of 32: K-step kt covers 32 channels of ONE filter tap, so each staged row is still one contiguous 128-byte run -- of
+// the tap's input pixel, or of a page of zeros when the tap falls into the padding (ReLU-on-load keeps zeros zero).
+template <int WM, int WN, int TM, int TN, bool UP2, bool RELU, bool KXK = false>
 __global__ __launch_bounds__(WM* WN * 64, 2) void gemm1x1_kernel(const ConvArgs p, const int epi_vec) {
   constexpr int NT = WM * WN * 64;
   constexpr int BM = WM * TM * 32;
@@ -82,14 +88,26 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void gemm1x1_kernel(const ConvArgs 
   // ---- per-thread DMA sources (fixed over K except for the k offset)
   const float* a_src[APASS];
   int a_slot[APASS];
+  int a_pix[KXK ? APASS : 1], a_ih0[KXK ? APASS : 1], a_iw0[KXK ? APASS : 1];   // KXK: frame base pixel, top-left tap
 #pragma unroll
   for (int ps = 0; ps < APASS; ++ps) {
     const int r = (tid >> 3) + ps * (NT / 8);       // row inside the tile; lane-linear LDS slot' = tid&7
     int m = m0 + r;
     m = m < M ? m : M - 1;
-    a_src[ps] = p.x + (size_t)m * p.ldx;
     a_slot[ps] = ((tid & 7) ^ (r & 7)) * 4;          // swizzle on the source side
+    if constexpr (KXK) {
+      const int n = m / (p.OH * p.OW);
+      const int rem = m - n * (p.OH * p.OW);
+      const int oh = rem / p.OW, ow = rem - oh * p.OW;
+      a_pix[ps] = n * p.H * p.W;
+      a_ih0[ps] = oh * p.SH - p.PT;
+      a_iw0[ps] = ow * p.SW - p.PL;
+      a_src[ps] = p.x;
+    } else {
+      a_src[ps] = p.x + (size_t)m * p.ldx;
+    }
   }
+  const int chunks_per_tap = KXK ? p.Cin / BK : 1;
   const float* b_src[BPASS];
 #pragma unroll
   for (int q = 0; q < BPASS; ++q) {
@@ -103,11 +121,26 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void gemm1x1_kernel(const ConvArgs 
   auto issue = [&](int kt, int stage) {
     float* sA = smem + stage * STAGE;
     float* sB = sA + BM * BK;
+    int kh = 0, kw = 0, c0 = 0;
+    if constexpr (KXK) {
+      const int tap = kt / chunks_per_tap;
+      c0 = (kt - tap * chunks_per_tap) * BK;
+      kh = tap / p.KW;
+      kw = tap - kh * p.KW;
+    }
 #pragma unroll
     for (int ps = 0; ps < APASS; ++ps) {
-      int k = kt * BK + a_slot[ps];
-      k = k < p.K ? k : 0;
-      __builtin_amdgcn_global_load_lds((gptr_t)(a_src[ps] + k), (lptr_t)(sA + (ps * NT + wave * 64) * 4), 16, 0, 0);
+      const float* src;
+      if constexpr (KXK) {
+        const int ih = a_ih0[ps] + kh, iw = a_iw0[ps] + kw;
+        const bool ok = (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W && kt * BK < p.K;
+        src = ok ? p.x + (size_t)(a_pix[ps] + ih * p.W + iw) * p.ldx + c0 + a_slot[ps] : g_zero_page + a_slot[ps];
+      } else {
+        int k = kt * BK + a_slot[ps];
+        k = k < p.K ? k : 0;
+        src = a_src[ps] + k;
+      }
+      __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(sA + (ps * NT + wave * 64) * 4), 16, 0, 0);
     }
 #pragma unroll
     for (int q = 0; q < BPASS; ++q)
@@ -208,13 +241,13 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void gemm1x1_kernel(const ConvArgs 
   conv_epilogue<WM, WN, TM, TN, UP2, true>(p, acc, smem, m0, n0, M, epi_vec, pre);
 }
 
-template <int WM, int WN, int TM, int TN, bool UP2, bool RELU>
+template <int WM, int WN, int TM, int TN, bool UP2, bool RELU, bool KXK = false>
 int launch_variant(const ConvArgs& a, int epi, unsigned tiles, hipStream_t s) {
   constexpr int BM = WM * TM * 32, BN = WN * TN * 32, NT = WM * WN * 64;
   constexpr int kStage = 2 * (BM * BK + BK * BN), kEpi = WM * WN * 32 * (TN * 32 + 4);
   constexpr size_t lds = (size_t)(kStage > kEpi ? kStage : kEpi) * sizeof(float);
   static_assert(lds <= 160 * 1024, "LDS budget");
-  auto kern = gemm1x1_kernel<WM, WN, TM, TN, UP2, RELU>;
+  auto kern = gemm1x1_kernel<WM, WN, TM, TN, UP2, RELU, KXK>;
   if (lds > 64 * 1024) {
     static bool once = (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
                                             (int)lds), true);
@@ -239,6 +272,9 @@ int launch_cfg(const ConvArgs& a, int epi, hipStream_t s) {
                         : launch_variant<WM, WN, TM, TN, true, false>(a, epi, t, s);
     }
   }
+  if (!(a.KH == 1 && a.KW == 1 && a.SH == 1 && a.SW == 1 && a.PT == 0 && a.PL == 0))
+    return a.pre_relu ? launch_variant<WM, WN, TM, TN, false, true, true>(a, epi, t, s)
+                      : launch_variant<WM, WN, TM, TN, false, false, true>(a, epi, t, s);
   return a.pre_relu ? launch_variant<WM, WN, TM, TN, false, true>(a, epi, t, s)
                     : launch_variant<WM, WN, TM, TN, false, false>(a, epi, t, s);
 }
@@ -246,9 +282,14 @@ int launch_cfg(const ConvArgs& a, int epi, hipStream_t s) {
 }  // namespace
 
 bool gemm1x1_eligible(const ConvArgs& a) {
-  return a.KH == 1 && a.KW == 1 && a.SH == 1 && a.SW == 1 && a.PT == 0 && a.PL == 0 && a.pre_scale == nullptr &&
-         a.H == a.OH && a.W == a.OW && a.Cin % 4 == 0 && a.ldx % 4 == 0 &&
-         (reinterpret_cast<uintptr_t>(a.x) & 15) == 0 && (reinterpret_cast<uintptr_t>(a.w) & 15) == 0;
+  const bool aligned = a.pre_scale == nullptr && a.ldx % 4 == 0 && (reinterpret_cast<uintptr_t>(a.x) & 15) == 0 &&
+                       (reinterpret_cast<uintptr_t>(a.w) & 15) == 0;
+  const bool pointwise = a.KH == 1 && a.KW == 1 && a.SH == 1 && a.SW == 1 && a.PT == 0 && a.PL == 0 &&
+                         a.H == a.OH && a.W == a.OW && a.Cin % 4 == 0;
+  // K x K: a K-step must not straddle filter taps, the up-sampling epilogue is only built for the pointwise form
+  const bool kxk = a.Cin % BK == 0 && !a.up2 && a.KH >= 1 && a.KW >= 1 && a.SH >= 1 && a.SW >= 1 && a.PT >= 0 &&
+                   a.PL >= 0;
+  return aligned && (pointwise || kxk);
 }
 
 int launch_gemm1x1(const ConvArgs& a, int cfg, int epi, hipStream_t s) {

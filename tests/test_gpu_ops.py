@@ -305,3 +305,31 @@ def test_conv2d_uint8_frames_normalised_on_load(k, s, cout, power, hip_lib, cuda
     _close(got, want, 2e-5, what='u8 conv vs fp64 oracle')
     with pytest.raises(Exception):
         F.conv2d(xb, w, strides=(s, s), in_lut=lut, tile_cfg=hip_lib.dh_conv2d_num_tile_cfgs() - 1)   # DMA GEMM: no u8
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('case', [
+    (2, 33, 31, 32, 64, 3, 3, 1, 'same'), (1, 32, 32, 64, 96, 3, 3, 2, 'same'), (2, 20, 24, 64, 64, 5, 1, 1, 'same'),
+    (2, 20, 24, 64, 64, 1, 5, 1, 'same'), (1, 12, 12, 32, 32, 3, 3, 1, 'valid'), (2, 17, 19, 96, 72, 5, 5, 2, 'same'),
+    (1, 16, 16, 192, 192, 3, 3, 2, 'same'), (2, 9, 9, 160, 64, 1, 1, 2, 'same')])
+@pytest.mark.parametrize('cfg', [9, 11, 12, 13, 15, 17])
+def test_kxk_conv_on_the_dma_kernel(case, cfg, hip_lib, cuda):
+    """K x K / strided / TF-SAME convolutions with Cin % 32 == 0 on the LDS-DMA kernel (taps in the zero padding
+    are fed from a page of zeros): bit-identical to the register-staged general kernel, with the fused ReLU
+    prologue + BN + residual epilogue, on every tiling."""
+    from deephar_amd import functional as F
+    n, h, w, cin, cout, kh, kw, s, pad = case
+    rng = np.random.default_rng(sum(v for v in case if isinstance(v, int)))
+    x = _rand(rng, (n, h, w, cin))
+    k = _rand(rng, (kh, kw, cin, cout), np.sqrt(1.0 / (kh * kw * cin)))
+    d = lambda a: torch.from_numpy(a).to(cuda)
+    base = F.conv2d(d(x), k, (s, s), pad, pre_relu=True, tile_cfg=8)
+    r1 = _rand(rng, tuple(base.shape))
+    qs, qb = _rand(rng, (cout,)), _rand(rng, (cout,))
+    kw_ = dict(pre_relu=True, post_scale=d(qs), post_shift=d(qb), res1=d(r1), post_relu=True)
+    a = F.conv2d(d(x), k, (s, s), pad, tile_cfg=cfg, **kw_)
+    b = F.conv2d(d(x), k, (s, s), pad, tile_cfg=cfg - 9, **kw_)
+    assert torch.equal(a, b)
+    ref = O.conv2d(O.relu(torch.from_numpy(x).double()), torch.from_numpy(k).double(), (s, s), pad)
+    ref = torch.relu(ref * torch.from_numpy(qs).double() + torch.from_numpy(qb).double() + torch.from_numpy(r1).double())
+    _close(a, ref, atol=5e-5, what='kxk dma conv')
