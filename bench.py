@@ -219,12 +219,14 @@ def main():
     # figure comes from the separate rocprofv3 --pmc passes recorded under profiles/ (same kernel, same shape)
     traffic, traffic_src = None, None
     pmc_path = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'pmc_dominant_kernel.json')
-    if os.path.exists(pmc_path) and dom_name.startswith('gemm1x1_kernel') and n == 64 and \
-            abs(dom['flops'] / dom['launches'] / 1e9 - 43.49) < 0.01:
+    main_shape_launches = sum(1 for s_ in plan.steps if s_.kind == 'conv' and kernel_name(s_) == dom_name and
+                              abs(s_.flops(n) / 1e9 - 43.49) < 0.01)
+    if os.path.exists(pmc_path) and dom_name.startswith('gemm1x1_kernel') and n == 64 and main_shape_launches:
         with open(pmc_path) as f:
             pmc = json.load(f)
         traffic = pmc['fetch_bytes_per_launch'] + pmc['write_bytes_per_launch']
-        traffic_src = pmc['source']
+        traffic_src = '%s (applies to the %d of %d launches of this kernel that are the 65536 x 576 x 576 GEMM)' % (
+            pmc['source'], main_shape_launches, dom['launches'])
 
     if rank == 0:
         value = world * n * args.steps / dt
