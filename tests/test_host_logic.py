@@ -255,3 +255,39 @@ def test_predict_validates_inputs_without_a_gpu():
         m.predict(np.zeros((2, 32, 32, 3), np.float32))
     with pytest.raises(ValueError):
         m.predict([np.zeros((2, 64, 64, 3), np.float32)] * 2)
+
+
+@pytest.mark.parametrize('nstreams', [1, 2, 3, 4])
+def test_multi_stream_memory_plan_is_race_free(nstreams):
+    """With parallel graph branches two buffers may share arena space only if EVERY access of one happens-before
+    every access of the other (data dependencies + same-stream order); cross-stream waits reference earlier steps
+    on other streams only, and every waited-for step records an event."""
+    from deephar_amd.engine import schedule
+    from deephar_amd.engine.planner import build_plan
+    m = _mpii(2)
+    plan = build_plan(m.inputs, m.outputs, nstreams=nstreams)
+    n = len(plan.steps)
+    stream = [s.stream for s in plan.steps]
+    assert max(stream) + 1 == plan.nstreams <= nstreams
+    deps = schedule.compute_deps(plan)
+    reach = schedule.happens_before(n, deps, stream)
+    acc = {}
+    for j, s in enumerate(plan.steps):
+        for v in list(s.ins.values()) + list(s.outs.values()):
+            if v is not None:
+                acc.setdefault(id(v.buf), (v.buf, set()))[1].add(j)
+    items = list(acc.values())
+    shared = 0
+    for i, (a, sa) in enumerate(items):
+        for b, sb in items[i + 1:]:
+            if a.offset + a.items <= b.offset or b.offset + b.items <= a.offset:
+                continue
+            shared += 1
+            a_before_b = all(all((reach[x] >> y) & 1 for y in sb) for x in sa)
+            b_before_a = all(all((reach[y] >> x) & 1 for x in sa) for y in sb)
+            assert a_before_b or b_before_a, 'unordered buffers share arena space'
+    assert shared > 50                                  # space is actually re-used
+    for j, s in enumerate(plan.steps):
+        for w in s.wait:
+            assert w < j and stream[w] != stream[j] and plan.steps[w].record
+        assert set(s.wait) <= set(deps[j])
