@@ -476,8 +476,35 @@ class Model(Layer):
     def summary(self, *a, **k):
         pass
 
-    def load_weights(self, *a, **k):
-        raise NotImplementedError
+    def load_weights(self, filepath, by_name=False):
+        """keras.engine.topology.load_weights_from_hdf5_group[_by_name] on a Keras-2 weight file."""
+        from deephar_amd import hdf5
+        f = hdf5.File(filepath)
+        root = f['model_weights'] if 'model_weights' in f else f
+        names = [n.decode() for n in np.atleast_1d(root.attrs['layer_names'])]
+        groups = []
+        for n in names:
+            wn = [w.decode() for w in np.atleast_1d(root[n].attrs['weight_names'])] if len(root[n].attrs['weight_names']) else []
+            if wn:
+                groups.append((n, [np.asarray(root[n][w]) for w in wn]))
+        layers = [l for l in keras_layers(self) if layer_weights(l)]
+        if by_name:
+            index = {}
+            for l in layers:
+                index.setdefault(l.name, []).append(l)
+            pairs = [(l, vals) for n, vals in groups for l in index.get(n, [])]
+        else:
+            if len(groups) != len(layers):
+                raise ValueError('You are trying to load a weight file containing %d layers into a model with %d layers.'
+                                 % (len(groups), len(layers)))
+            pairs = list(zip(layers, [vals for _, vals in groups]))
+        for layer, vals in pairs:
+            slots = layer_weights(layer)
+            if len(slots) != len(vals):
+                raise ValueError('Layer %s expects %d weights, got %d' % (layer.name, len(slots), len(vals)))
+            for (_, owner, i), v in zip(slots, vals):
+                assert tuple(owner.weights[i].shape) == tuple(v.shape), (layer.name, owner.name, v.shape)
+                owner.weights[i] = torch.from_numpy(np.ascontiguousarray(v)).to(DTYPE[0])
 
 
 # ------------------------------------------------------------------------------------------------- backend

@@ -2,6 +2,8 @@
 activations.py, models/*.py imported unmodified and executed on oracle/refrun/minikeras.py; generated in the build
 container by tests/golden/make_reference_golden.py).  This is what pins the oracle's graph wiring, layer order,
 constants and output ordering to the reference; Keras/TF layer semantics remain restated."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -21,3 +23,40 @@ def test_oracle_matches_reference_code(tag):
     o32 = run(torch.float32)
     for k, (a, b) in enumerate(zip(o32, g32)):
         assert np.abs(a - b).max() <= 2e-5 * max(1.0, np.abs(b).max()), (tag, k, np.abs(a - b).max())
+
+
+@pytest.mark.skipif(not os.path.isdir('/root/reference/deephar'), reason='needs the reference checkout')
+def test_keras_parity_kit_round_trip(tmp_path):
+    """tools/make_keras_parity_kit.py: the product's weights in Keras' file layout, loaded BY ORDER into the
+    reference's own model (here on mini-keras standing in for Keras 2.1.4) by the kit's runner script, reproduce
+    the committed golden outputs exactly -- i.e. the kit is ready for a machine with the real Keras / TF."""
+    import importlib.util
+    import runpy
+    import sys
+    import types
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, 'tests', 'golden'))
+    sys.path.insert(0, os.path.join(root, 'tools'))
+    import make_keras_parity_kit as kit
+    import make_reference_golden as G
+    kit.main(str(tmp_path), ['rec2d'])
+    saved = {k: sys.modules.get(k) for k in list(sys.modules) if k == 'keras' or k.startswith('keras.') or
+             k == 'deephar' or k.startswith('deephar.') or k == 'tensorflow'}
+    try:
+        G.load_reference()
+        spec = importlib.util.spec_from_file_location('deephar.utils.pose', '/root/reference/deephar/utils/pose.py')
+        pose = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(pose)
+        u = types.ModuleType('deephar.utils')
+        u.pa16j2d, u.pa17j3d = pose.pa16j2d, pose.pa17j3d
+        sys.modules['deephar.utils'] = u
+        runpy.run_path(str(tmp_path / 'run_in_keras.py'), run_name='__main__')
+    finally:
+        for k in [k for k in sys.modules if k == 'keras' or k.startswith('keras.') or k == 'deephar' or
+                  k.startswith('deephar.') or k == 'tensorflow']:
+            del sys.modules[k]
+        sys.modules.update({k: v for k, v in saved.items() if v is not None})
+    out = np.load(str(tmp_path / 'keras_outputs.npz'))
+    g32, _ = golden('rec2d')
+    for i, a in enumerate(g32):
+        assert np.array_equal(out['rec2d/%d' % i], a)
