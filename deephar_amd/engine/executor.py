@@ -533,6 +533,7 @@ class Executor:
         self.tune_table = {}
         self.store = WeightStore(self.device)
         self.bound = {}
+        self._wstamp = None        # sum of Param.version over plan.params at the last refresh / first bind
         with torch.cuda.device(self.device):
             self.stream = torch.cuda.Stream(device=self.device)
 
@@ -554,9 +555,24 @@ class Executor:
             self.bound[key] = bp
         return bp
 
+    def _weight_stamp(self):
+        return sum(p.version for p in self.plan.params)
+
+    def sync_weights(self):
+        """Device weights follow the host Params: any Param.set since the last forward (Model.set_weights,
+        Layer.set_weights, load_weights through ANOTHER model that shares these layers, init_synthetic ...) bumps
+        its version; the sum over the plan's params is compared before every forward and changed tensors are
+        re-packed and copied in place (pointers stay valid, captured graphs need no re-capture)."""
+        stamp = self._weight_stamp()
+        if self._wstamp is None:
+            self._wstamp = stamp
+        elif stamp != self._wstamp:
+            self.refresh_weights()
+
     def refresh_weights(self):
         """Push changed Params to their (already bound) device tensors in place."""
         torch = _torch()
+        self._wstamp = self._weight_stamp()
         with torch.cuda.device(self.device), torch.cuda.stream(self.stream):
             for s in self.plan.steps:
                 for role, p in s.params.items():
@@ -605,7 +621,11 @@ class Executor:
         m = arrays[0].shape[0]
         n = n or m
         with torch.cuda.device(self.device), torch.cuda.stream(self.stream):
+            if self.bound:
+                self.sync_weights()
             bp = self.bind(n, u8_norm=u8_norm)
+            if self._wstamp is None:
+                self._wstamp = self._weight_stamp()
             self.set_inputs(bp, arrays)
             self.forward(bp)
             outs = [bp.tensor(v)[:m].contiguous().cpu() for v in self.plan.outputs]

@@ -163,3 +163,21 @@ def load_weights(model, path, by_name=False):
     for p in params:
         if p.key in have:
             p.set(data[p.key])
+
+
+def rescale_layers(model, factors):
+    """Multiply the kernels of the named conv layers by a factor: {layer name: factor}.  Used by the parity tests to
+    bring the heat-map heads of a synthetic SPNet to the logit spread `init_synthetic` aims for (its closed-form
+    variance propagation drifts over SPNet's lateral / re-injection sums: measured std 4 .. 18 for a target of 6;
+    SURVEY.md 8d asks for O(1-10)).  The measurement comes from the caller -- this module never runs a model."""
+    done = set()
+    for n in model._nodes:
+        for layer in n.layers.values():
+            if layer.name in factors and id(layer) not in done:
+                done.add(id(layer))
+                p = layer.params[0]
+                p.set(p.value * np.float32(factors[layer.name]))
+    missing = set(factors) - {l.name for n in model._nodes for l in n.layers.values()}
+    if missing:
+        raise KeyError('no such layers: %s' % sorted(missing))
+    return model

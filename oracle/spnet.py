@@ -71,22 +71,27 @@ def entry_flow(W, x, growth=96, image_div=8):
     return x
 
 
-def prediction_branch(W, x, num_joints, name, pred_activate=True, forward_maps=True, reinject=True):
-    """spnet.prediction_branch (spnet.py:24-48), replica=None.  `reinject=False` for the very last block of the
-    model: its re-injection convs are created by the reference but are not reachable from any model output,
-    so Keras drops them from the Model (no weights exist for them)."""
+def prediction_branch(W, x, num_joints, name, pred_activate=True, forward_maps=True, reinject=True,
+                      replica=False):
+    """spnet.prediction_branch (spnet.py:24-48).  `replica` (spnet.py:36-38): a second, independently weighted
+    1x1 conv '<name>_conv1_replica' on the same activated input; its maps feed the ACTION stream only
+    (spnet.py:216,224), the pose stream and the re-injection keep using '<name>_conv1'.
+    `reinject=False` for the very last block of the model: its re-injection convs are created by the reference
+    but are not reachable from any model output, so Keras drops them from the Model (no weights exist for them).
+    Returns (re-injected features | None, prediction maps, replica maps | None)."""
     nf = x.shape[-1]
     x = ops.relu(x)
     pred_maps = _conv(W, x, num_joints, (1, 1), name + '_conv1')
+    rep = _conv(W, x, num_joints, (1, 1), name + '_conv1_replica') if replica else None
     if not reinject:
-        return None, pred_maps
+        return None, pred_maps, rep
     if forward_maps:
         x = torch.cat([_conv(W, x, num_joints, (1, 1), name + '_fw_maps'), pred_maps], dim=-1)
     else:
         x = pred_maps
     if pred_activate:
         x = ops.relu(x)
-    return _conv(W, x, nf, (1, 1), name + '_conv2'), pred_maps
+    return _conv(W, x, nf, (1, 1), name + '_conv2'), pred_maps, rep
 
 
 def keypoint_confidence(h):
@@ -147,9 +152,12 @@ class _State:
     pass
 
 
-def forward(weights, clips, cfg, dtype=torch.float32):
+def forward(weights, clips, cfg, dtype=torch.float32, taps=None):
     """spnet.build(cfg) + predict.  cfg: dict(num_joints, dim, num_actions, num_pyramids, action_pyramids,
-    num_levels, kernel_size, growth, image_div, num_pose_features, num_visual_features, sam_alpha).
+    num_levels, kernel_size, growth, image_div, num_pose_features, num_visual_features, sam_alpha
+    [, pose_replica=False]).
+    taps: optional dict, filled with '<prediction block>/logits' = heat-map logits [N*T, h, w, J] and, for 3-D
+    models, '<prediction block>/dlogits' = depth-map logits (numpy).
     clips: [N, T, H, W, 3] (or [N, H, W, 3]).  Returns poses [N,(T,)J,dim+1] ... then action scores [N, A] ..."""
     W = weights if isinstance(weights, Weights) else Weights(weights, dtype)
     W.reset()
@@ -173,26 +181,32 @@ def forward(weights, clips, cfg, dtype=torch.float32):
             xp = _sepconv(W, xp, nf, ks, name + '_conv1')
             reinject.append(xp)
             xp = _bn(W, xp, name + '_bn2')
-            x1, org_h = prediction_branch(W, xp, J, name + '_heatmaps', pred_activate=True,
-                                          reinject=not last_pose)
+            replica = bool(cfg.get('pose_replica', False)) and do_action          # spnet.py:160
+            x1, org_h, rep_h = prediction_branch(W, xp, J, name + '_heatmaps', pred_activate=True,
+                                                 reinject=not last_pose, replica=replica)
             reinject.append(x1)
+            if taps is not None:
+                taps[name + '/logits'] = org_h.numpy().copy()
             h = ops.channel_softmax_2d(org_h, alpha)
             p = ops.softargmax2d_from_prob(h)
             c = keypoint_confidence(h)
             if dim == 3:
-                x1, org_d = prediction_branch(W, xp, J, name + '_depthmaps', pred_activate=False,
-                                              forward_maps=False, reinject=not last_pose)
+                x1, org_d, rep_d = prediction_branch(W, xp, J, name + '_depthmaps', pred_activate=False,
+                                                     forward_maps=False, reinject=not last_pose, replica=replica)
                 reinject.append(x1)
+                if taps is not None:
+                    taps[name + '/dlogits'] = org_d.numpy().copy()
                 z = (torch.sigmoid(org_d) * h).sum(dim=(1, 2)).unsqueeze(-1)
                 p = torch.cat([p, z], dim=-1)
             if do_action:
                 st.act_cnt += 1
                 act = 'act%d' % st.act_cnt
-                act_h = ops.channel_softmax_2d(org_h, alpha)
+                act_h = ops.channel_softmax_2d(rep_h if replica else org_h, alpha)       # spnet.py:216-218
                 act_p = ops.softargmax2d_from_prob(act_h)
                 act_c = keypoint_confidence(act_h)
                 if dim == 3:
-                    act_z = (torch.sigmoid(org_d) * act_h).sum(dim=(1, 2)).unsqueeze(-1)
+                    act_d = rep_d if replica else org_d                                  # spnet.py:224
+                    act_z = (torch.sigmoid(act_d) * act_h).sum(dim=(1, 2)).unsqueeze(-1)
                     act_p = torch.cat([act_p, act_z], dim=-1)
                 af = ops.kronecker_prod(act_h, zp)
                 unfold = lambda v: v.reshape((n, t) + tuple(v.shape[1:]))

@@ -33,3 +33,14 @@ def cuda():
     if not torch.cuda.is_available():
         pytest.fail('-m gpu tests need a HIP device; none visible')
     return torch.device('cuda:0')
+
+
+def pytest_sessionfinish(session, exitstatus):
+    """-m gpu runs: write the per-output parity table (tests/paritylog.py) to gpurun_out/parity_r02.json."""
+    try:
+        import paritylog
+        path = paritylog.dump()
+        if path:
+            print('\nparity table: %s (%d comparisons)' % (path, len(paritylog.RECORDS)))
+    except Exception as e:      # never turn a green run red over the report
+        print('parity table not written:', e)

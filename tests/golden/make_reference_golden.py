@@ -108,7 +108,7 @@ def draw(tag, shape):
     return np.random.default_rng(seed).uniform(-1, 1, shape)
 
 
-TAGS = ('rec2d', 'rec3d', 'merge2d', 'merge3d', 'spnet3d', 'spnet2d')
+TAGS = ('rec2d', 'rec3d', 'merge2d', 'merge3d', 'spnet3d', 'spnet2d', 'spnet2dr')
 
 
 def build_pair(R, tag):
@@ -143,16 +143,19 @@ def build_pair(R, tag):
         prod = pact.build_merge_model(prod_pe, 15, (128, 128, 3), T, J, 2, pose_dim=dim, depth_maps=8,
                                       pose_net_version=ver, output_poses=True)
         return ref, prod, draw(tag, (2, T, 128, 128, 3))
-    # SPNet: NTU-like 3-D (T=4, time_stride 1) and Penn-like 2-D (T=16, time_stride 2, frame/joint padding)
-    T, lay, nact, pyr, apyr, feats, res = {'spnet3d': (4, 'pa17j3d', 60, 2, [1, 2], 192, 128),
-                                           'spnet2d': (16, 'pa16j2d', 15, 2, [2], 160, 128)}[tag]
+    # SPNet: NTU-like 3-D (T=4, time_stride 1), Penn-like 2-D (T=16, time_stride 2, frame/joint padding) and the
+    # shipped PennAction multitask configuration (exp/pennaction/eval_penn_multitask.py:36-40: T=8, 6 pyramids,
+    # actions on pyramids 5 and 6, pose_replica=True -> '<pb>_heatmaps_conv1_replica' feeds the action stream)
+    T, lay, nact, pyr, apyr, feats, res, rep = {'spnet3d': (4, 'pa17j3d', 60, 2, [1, 2], 192, 128, False),
+                                                'spnet2d': (16, 'pa16j2d', 15, 2, [2], 160, 128, False),
+                                                'spnet2dr': (8, 'pa16j2d', 15, 6, [5, 6], 160, 128, True)}[tag]
     R['models.spnet'].__dict__.pop('act_cnt', None)       # the reference's process-global counter
     rcfg = R['config'].ModelConfig((T, res, res, 3), getattr(putils, lay), num_actions=[nact], num_pyramids=pyr,
-                                   action_pyramids=apyr, num_levels=4, pose_replica=False,
+                                   action_pyramids=apyr, num_levels=4, pose_replica=rep,
                                    num_pose_features=feats, num_visual_features=feats)
     ref = R['models.spnet'].build(rcfg)
     pcfg = pconfig.ModelConfig((T, res, res, 3), getattr(putils, lay), num_actions=[nact], num_pyramids=pyr,
-                               action_pyramids=apyr, num_levels=4, pose_replica=False, num_pose_features=feats,
+                               action_pyramids=apyr, num_levels=4, pose_replica=rep, num_pose_features=feats,
                                num_visual_features=feats)
     prod = pspn.build(pcfg)
     return ref, prod, draw(tag, (1, T, res, res, 3))

@@ -47,23 +47,24 @@ def build_case(tag):
         okw = dict(pose_dim=dim, depth_maps=8, pose_net_version=ver, output_poses=True,
                    num_context_per_joint=2 if dim == 2 else 0)
         run = lambda wd, dt: oact.forward_merge(wd, x, 15, J, 2, dtype=dt, **okw)
-    elif tag in ('spnet3d', 'spnet2d'):
-        T, lay, nact, pyr, apyr, feats = (4, 'pa17j3d', 60, 2, [1, 2], 192) if tag == 'spnet3d' else \
-            (16, 'pa16j2d', 15, 2, [2], 160)
+    elif tag in ('spnet3d', 'spnet2d', 'spnet2dr'):
+        T, lay, nact, pyr, apyr, feats, rep = {'spnet3d': (4, 'pa17j3d', 60, 2, [1, 2], 192, False),
+                                               'spnet2d': (16, 'pa16j2d', 15, 2, [2], 160, False),
+                                               'spnet2dr': (8, 'pa16j2d', 15, 6, [5, 6], 160, True)}[tag]
         layout = getattr(utils, lay)
         cfg = ModelConfig((T, 128, 128, 3), layout, num_actions=[nact], num_pyramids=pyr, action_pyramids=apyr,
-                          num_levels=4, pose_replica=False, num_pose_features=feats, num_visual_features=feats)
+                          num_levels=4, pose_replica=rep, num_pose_features=feats, num_visual_features=feats)
         m = spnet.build(cfg)
         x = case_input(tag, (1, T, 128, 128, 3))
         ocfg = dict(num_joints=layout.num_joints, dim=layout.dim, num_actions=[nact], num_pyramids=pyr,
                     action_pyramids=apyr, num_levels=4, kernel_size=(5, 5), growth=96, image_div=8,
-                    num_pose_features=feats, num_visual_features=feats, sam_alpha=1)
-        run = lambda wd, dt: osp.forward(wd, x, ocfg, dtype=dt)
+                    num_pose_features=feats, num_visual_features=feats, sam_alpha=1, pose_replica=rep)
+        run = lambda wd, dt, taps=None: osp.forward(wd, x, ocfg, dtype=dt, taps=taps)
     else:
         raise KeyError(tag)
     weights.init_synthetic(m, seed=0)
     wd = weights.as_dict(m)
-    return m, x, (lambda dt: run(wd, dt))
+    return m, x, (lambda dt, **kw: run(wd, dt, **kw))
 
 
-CASES = ['rec2d', 'rec3d', 'merge2d', 'merge3d', 'spnet3d', 'spnet2d']
+CASES = ['rec2d', 'rec3d', 'merge2d', 'merge3d', 'spnet3d', 'spnet2d', 'spnet2dr']

@@ -2,20 +2,23 @@
 on identical seeded weights and inputs, plus size-independent properties at the BASELINE batch sizes.
 
 Tolerance (BASELINE.json north_star): joint coordinates within 1e-3 px of a 256-px crop, i.e.
-|d| <= 3.9e-6 in the model's normalised [0,1] output.  Two different fp32 summation orders through ~150 conv
-layers are only comparable against an fp64 arbiter (SURVEY.md section 7 "hard parts"), so each test measures
-    e_hip = max|hip - oracle_fp64|     and     e_cpu = max|oracle_fp32 - oracle_fp64|
-and requires e_hip <= max(PX_TOL, FACTOR * e_cpu): the HIP path must be within 1e-3 px of the truth, or --
-where plain fp32 itself cannot get that close -- no further from it than FACTOR x the fp32 CPU path is.
+|d| <= 3.9e-6 in the model's normalised [0,1] output, asserted as max|hip - oracle_fp64| <= 1e-3 px with no
+relative clause (tests/paritylog.py; every comparison also lands in gpurun_out/parity_r02.json together with
+|oracle_fp32 - oracle_fp64| and |hip - oracle_fp32|).  SPNet's synthetic heat-maps are the one place where the
+read-out itself is ill-conditioned; see paritylog.conditioned_tolerance for the a-priori bound used there.
 """
+import os
+import sys
+
 import numpy as np
 import pytest
 import torch
 
-pytestmark = pytest.mark.gpu
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import paritylog                                   # noqa: E402
+from paritylog import PX_TOL, check as _check      # noqa: E402
 
-PX_TOL = 1e-3 / 256.0   # 1e-3 px in normalised units
-FACTOR = 3.0
+pytestmark = pytest.mark.gpu
 
 
 def _build(dim, num_blocks, joints, **kw):
@@ -32,16 +35,6 @@ def _oracle(wd, x, dim, num_blocks, joints, dtype, **kw):
     taps = {}
     outs = oref.forward(wd, x, joints, dim, num_blocks=num_blocks, ksize=(5, 5), dtype=dtype, taps=taps, **kw)
     return outs, taps
-
-
-def _check(name, hip, o32, o64, tol, rel=False):
-    scale = np.maximum(np.abs(o64), 1.0) if rel else 1.0
-    e_hip = float(np.max(np.abs(hip - o64) / scale))
-    e_cpu = float(np.max(np.abs(o32 - o64) / scale))
-    lim = max(tol, FACTOR * e_cpu)
-    print('%-12s e_hip=%.3e (%.2e px)  e_cpu32=%.3e  limit=%.3e' % (name, e_hip, 256 * e_hip, e_cpu, lim))
-    assert e_hip <= lim, '%s: HIP error %.3e exceeds %.3e (fp32 CPU error %.3e)' % (name, e_hip, lim, e_cpu)
-    return e_hip, e_cpu
 
 
 def test_reception_mpii_2d_context_parity(hip_lib, cuda):
@@ -146,6 +139,29 @@ def test_predict_accepts_float64_and_partial_batches(hip_lib, cuda):
         m.predict(np.zeros((2, 128, 128, 3), np.float32))
 
 
+def test_weights_changed_after_first_predict_are_used(hip_lib, cuda):
+    """device weights must follow Param.set / Layer.set_weights / Model.set_weights made AFTER the first
+    predict, also for batch sizes that were bound before the change and for a second Model sharing the layers."""
+    from deephar_amd import Model, weights
+    m, _ = _build(2, 1, 16, num_context_per_joint=2)
+    x = np.random.default_rng(8).uniform(-1, 1, (2, 256, 256, 3)).astype(np.float32)
+    first = m.predict(x, batch_size=2)
+    tail = Model(m.input, m.outputs[-1])              # shares every layer with m, own executor
+    assert np.array_equal(tail.predict(x, batch_size=2), first)
+    weights.init_synthetic(m, seed=5)                 # new values for every Param, same objects
+    second = m.predict(x, batch_size=2)               # batch size 2 was bound with the OLD weights
+    assert not np.array_equal(first, second)
+    o64, _ = _oracle(weights.as_dict(m), x, 2, 1, 16, torch.float64, num_context_per_joint=2)
+    o32, _ = _oracle(weights.as_dict(m), x, 2, 1, 16, torch.float32, num_context_per_joint=2)
+    _check('reloaded.xy', second[..., :2], o32[0][..., :2], o64[0][..., :2], PX_TOL)
+    assert np.array_equal(tail.predict(x, batch_size=2), second)     # the sharing model sees the change too
+    assert np.array_equal(m.predict(x[:1], batch_size=1), second[:1])  # a newly bound batch size as well
+    vals = [v.copy() for v in m.get_weights()]
+    vals[0] = vals[0] * np.float32(0.5)
+    m.set_weights(vals)
+    assert not np.array_equal(m.predict(x, batch_size=2), second)
+
+
 def _merge(pose_dim, T, joints, blocks, **kw):
     from deephar_amd import graph, weights
     from deephar_amd.models import reception, action
@@ -187,48 +203,71 @@ def test_merge_action_model_parity(pose_dim, joints, version, hip_lib, cuda):
         np.testing.assert_allclose(hip[k].sum(-1), 1.0, rtol=1e-5)
 
 
-def _spnet(T, layout, num_actions, pyramids, action_pyramids, feats):
+def _spnet(T, layout, num_actions, pyramids, action_pyramids, feats, replica=False, calibrate=None):
+    """calibrate: frames [N, T, 256, 256, 3] -> heat-map heads are brought to logit std ~ 6 before the weights are
+    read out (paritylog.calibrate_spnet_heads)."""
     from deephar_amd import graph, weights, utils
     from deephar_amd.config import ModelConfig
     from deephar_amd.models import spnet
     graph.reset_naming()
     lay = getattr(utils, layout)
     cfg = ModelConfig((T, 256, 256, 3), lay, num_actions=[num_actions], num_pyramids=pyramids,
-                      action_pyramids=action_pyramids, num_levels=4, pose_replica=False, num_pose_features=feats,
+                      action_pyramids=action_pyramids, num_levels=4, pose_replica=replica, num_pose_features=feats,
                       num_visual_features=feats)
     m = spnet.build(cfg)
     weights.init_synthetic(m, seed=0)
     ocfg = dict(num_joints=lay.num_joints, dim=lay.dim, num_actions=[num_actions], num_pyramids=pyramids,
                 action_pyramids=action_pyramids, num_levels=4, kernel_size=(5, 5), growth=96, image_div=8,
-                num_pose_features=feats, num_visual_features=feats, sam_alpha=1)
+                num_pose_features=feats, num_visual_features=feats, sam_alpha=1, pose_replica=replica)
+    if calibrate is not None:
+        paritylog.calibrate_spnet_heads(m, ocfg, calibrate)
     return m, cfg, weights.as_dict(m), ocfg
 
 
-@pytest.mark.parametrize('T,layout,nact,pyr,apyr,feats', [
-    (8, 'pa17j3d', 60, 2, [1, 2], 192),     # exp/ntu/eval_ntu_multitask.py:35-38 (cfg 5 family), time_stride 1
-    (16, 'pa16j2d', 15, 2, [2], 160),       # Penn-like 2-D, T>=16 -> time_stride 2, action only on pyramid 2
-])
-def test_spnet_multitask_parity(T, layout, nact, pyr, apyr, feats, hip_lib, cuda):
-    """SPNet pose + action outputs vs the oracle; split_model() slices the same numbers."""
-    from deephar_amd.models import spnet, split_model
+def spnet_parity(m, cfg, wd, ocfg, x, pyr, apyr, case=None):
+    """Shared body of the SPNet parity tests: poses through the conditioned 1e-3 px check, action scores + labels."""
+    from deephar_amd.models import spnet
     from oracle import spnet as osp
-    m, cfg, wd, ocfg = _spnet(T, layout, nact, pyr, apyr, feats)
-    x = np.random.default_rng(11).uniform(-1, 1, (1, T, 256, 256, 3)).astype(np.float32)
-    hip = m.predict(x, batch_size=1)
+    hip = m.predict(x, batch_size=len(x))
+    t64 = {}
     o32 = osp.forward(wd, x, ocfg, dtype=torch.float32)
-    o64 = osp.forward(wd, x, ocfg, dtype=torch.float64)
+    o64 = osp.forward(wd, x, ocfg, dtype=torch.float64, taps=t64)
     npose = spnet.get_num_predictions(pyr, 4)
     nact_out = spnet.get_num_predictions(len(apyr), 4)
     assert len(hip) == npose + nact_out and [h.shape for h in hip] == [o.shape for o in o64]
     dim = ocfg['dim']
-    for k in range(npose):
-        _check('pose%d.xy' % k, hip[k][..., :2], o32[k][..., :2], o64[k][..., :2], PX_TOL)
+    blocks = [k[:-len('/logits')] for k in t64 if k.endswith('/logits')]
+    assert len(blocks) == npose
+    for k, b in enumerate(blocks):
+        std = float(t64[b + '/logits'].std())
+        assert 1.0 < std < 30.0, 'heat-map logits of %s are flat or one-hot (std %.2f): vacuous test' % (b, std)
+        tol_xy, tol_z = paritylog.conditioned_tolerance(t64[b + '/logits'], t64.get(b + '/dlogits'))
+        flat = lambda a: a.reshape((-1,) + a.shape[-2:])
+        h, a32, a64 = flat(hip[k]), flat(o32[k]), flat(o64[k])
+        paritylog.check_conditioned('%s.xy' % b, h[..., :2], a32[..., :2], a64[..., :2], tol_xy, case=case)
         if dim == 3:
-            _check('pose%d.z' % k, hip[k][..., 2], o32[k][..., 2], o64[k][..., 2], PX_TOL)
-        _check('pose%d.c' % k, hip[k][..., dim], o32[k][..., dim], o64[k][..., dim], 2e-6)
+            paritylog.check_conditioned('%s.z' % b, h[..., 2], a32[..., 2], a64[..., 2], tol_z, case=case)
+        _check('%s.conf' % b, h[..., dim], a32[..., dim], a64[..., dim], 2e-6, case=case)
     for k in range(npose, npose + nact_out):
-        _check('action%d' % (k - npose), hip[k], o32[k], o64[k], 1e-5)
+        _check('action%d' % (k - npose), hip[k], o32[k], o64[k], 1e-5, case=case)
         assert np.array_equal(hip[k].argmax(-1), o64[k].argmax(-1))
+    return hip
+
+
+@pytest.mark.parametrize('T,layout,nact,pyr,apyr,feats,replica', [
+    (8, 'pa17j3d', 60, 2, [1, 2], 192, False),     # exp/ntu/eval_ntu_multitask.py:35-38 (cfg 5 family), time_stride 1
+    (16, 'pa16j2d', 15, 2, [2], 160, False),       # Penn-like 2-D, T>=16 -> time_stride 2, action only on pyramid 2
+    (8, 'pa16j2d', 15, 6, [5, 6], 160, True),      # exp/pennaction/eval_penn_multitask.py:36-40 as shipped: 6 pyramids,
+                                                   # actions on 5 and 6, pose_replica=True (18 pose + 6 action outputs)
+])
+def test_spnet_multitask_parity(T, layout, nact, pyr, apyr, feats, replica, hip_lib, cuda):
+    """SPNet pose + action outputs vs the oracle; split_model() slices the same numbers."""
+    from deephar_amd.models import spnet, split_model
+    x = np.random.default_rng(11).uniform(-1, 1, (1, T, 256, 256, 3)).astype(np.float32)
+    m, cfg, wd, ocfg = _spnet(T, layout, nact, pyr, apyr, feats, replica=replica, calibrate=x)
+    hip = spnet_parity(m, cfg, wd, ocfg, x, pyr, apyr)
+    npose = spnet.get_num_predictions(pyr, 4)
+    nact_out = spnet.get_num_predictions(len(apyr), 4)
     pose_model, act_model = split_model(m, cfg)
     a = act_model.predict(x, batch_size=1)
     a = a if isinstance(a, list) else [a]
@@ -236,6 +275,28 @@ def test_spnet_multitask_parity(T, layout, nact, pyr, apyr, feats, hip_lib, cuda
         assert np.array_equal(a[k], hip[npose + k])
     last = pose_model.predict(x, batch_size=1)[-1]
     assert np.array_equal(last, hip[npose - 1])
+
+
+def test_spnet_replica_feeds_only_the_action_stream(hip_lib, cuda):
+    """pose_replica=True (spnet.py:36-38,160,216,224): the '<pb>_heatmaps_conv1_replica' maps drive the action heads
+    and nothing else -- perturbing a replica kernel changes action scores but no pose output bit; perturbing the
+    matching '_conv1' kernel changes the poses."""
+    x = np.random.default_rng(12).uniform(-1, 1, (1, 4, 256, 256, 3)).astype(np.float32)
+    m, cfg, _, _ = _spnet(4, 'pa16j2d', 15, 2, [2], 160, replica=True)
+    base = m.predict(x, batch_size=1)
+    npose = 6
+    names = {l.name: l for n in m._nodes for l in n.layers.values()}
+    assert 'up2_pb2_heatmaps_conv1_replica' in names and 'dp1_pb1_heatmaps_conv1_replica' not in names
+    lay = names['up2_pb2_heatmaps_conv1_replica']
+    lay.set_weights([lay.get_weights()[0] * np.float32(1.5)])
+    pert = m.predict(x, batch_size=1)
+    for k in range(npose):
+        assert np.array_equal(base[k], pert[k]), 'pose output %d moved with a replica kernel' % k
+    assert any(not np.array_equal(base[k], pert[k]) for k in range(npose, len(base)))
+    lay = names['up2_pb2_heatmaps_conv1']
+    lay.set_weights([lay.get_weights()[0] * np.float32(1.5)])
+    pert2 = m.predict(x, batch_size=1)
+    assert not np.array_equal(pert2[3], pert[3])
 
 
 def test_frame_sharded_stages_match_full_model(hip_lib, cuda):
@@ -278,7 +339,7 @@ def test_frame_sharded_stages_match_full_model(hip_lib, cuda):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize('tag', ['rec2d', 'rec3d', 'merge2d', 'merge3d', 'spnet3d', 'spnet2d'])
+@pytest.mark.parametrize('tag', ['rec2d', 'rec3d', 'merge2d', 'merge3d', 'spnet3d', 'spnet2d', 'spnet2dr'])
 def test_hip_matches_reference_code_goldens(tag, hip_lib, cuda):
     """HIP engine vs the committed golden vectors that were computed by the reference's OWN model code
     (tests/golden/make_reference_golden.py): coordinates within max(1e-3 px, 3 x the fp32 error of that same code),
@@ -286,11 +347,20 @@ def test_hip_matches_reference_code_goldens(tag, hip_lib, cuda):
     import sys, os
     sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
     from refgolden import build_case, golden
-    m, x, _ = build_case(tag)
+    m, x, run = build_case(tag)
     g32, g64 = golden(tag)
     hip = m.predict(x.astype(np.float32), batch_size=len(x))
     hip = hip if isinstance(hip, list) else [hip]
     assert [h.shape for h in hip] == [g.shape for g in g64]
+    tols = None
+    if tag.startswith('spnet'):
+        # the golden weights are init_synthetic's un-calibrated ones (logit std up to ~18 on the coarse levels):
+        # conditioning-aware tolerance from the fp64 oracle's logits (paritylog.conditioned_tolerance); the oracle
+        # agrees with these goldens to 1e-9 (tests/test_reference_golden.py)
+        t64 = {}
+        run(torch.float64, taps=t64)
+        tols = [paritylog.conditioned_tolerance(t64[k], t64.get(k[:-len('/logits')] + '/dlogits'))
+                for k in t64 if k.endswith('/logits')]
     for k, (h, a, b) in enumerate(zip(hip, g32, g64)):
         is_scores = b.ndim == 2 and tag.startswith(('merge', 'spnet'))
         is_maps = b.ndim == 4 and tag == 'rec3d'
@@ -299,6 +369,14 @@ def test_hip_matches_reference_code_goldens(tag, hip_lib, cuda):
             assert np.array_equal(h.argmax(-1), b.argmax(-1))
         elif is_maps:
             _check('%s.maps%d' % (tag, k), h, a, b, 2e-5, rel=True)
+        elif tols is not None:
+            flat = lambda v: v.reshape((-1,) + v.shape[-2:])
+            dim = b.shape[-1] - 1
+            txy, tz = tols[k]
+            paritylog.check_conditioned('%s.out%d.xy' % (tag, k), flat(h)[..., :2], flat(a)[..., :2], flat(b)[..., :2], txy)
+            if dim == 3:
+                paritylog.check_conditioned('%s.out%d.z' % (tag, k), flat(h)[..., 2], flat(a)[..., 2], flat(b)[..., 2], tz)
+            _check('%s.out%d.c' % (tag, k), h[..., dim], a[..., dim], b[..., dim], 2e-6)
         else:
             _check('%s.out%d' % (tag, k), h, a, b, PX_TOL if b.shape[-1] != 1 else 1e-5, rel=(b.shape[-1] == 1))
 
@@ -345,7 +423,7 @@ def test_ragged_batches_and_chunking(hip_lib, cuda):
         assert np.array_equal(a[3:4], b)
 
 
-@pytest.mark.parametrize('tag', ['rec2d', 'rec3d', 'merge2d', 'merge3d', 'spnet3d', 'spnet2d'])
+@pytest.mark.parametrize('tag', ['rec2d', 'rec3d', 'merge2d', 'merge3d', 'spnet3d', 'spnet2d', 'spnet2dr'])
 def test_hip_matches_real_keras_outputs(tag, hip_lib, cuda):
     """The day tests/golden/keras_outputs.npz exists (produced on a machine with keras==2.1.4 + tensorflow==1.6 by
     the kit of tools/make_keras_parity_kit.py) this pins the remaining restated numerics -- TF-SAME padding, BN
