@@ -51,7 +51,9 @@ def conditioned_tolerance(logits64, dlogits64=None):
     the first-order image of a fixed ULP_BUDGET-ulp logit error elsewhere:
         tol = min(3e-3 px, max(1e-3 px, S * ULP_BUDGET * ulp32(max|logit|))).
     It is an a-priori bound computed from the fp64 oracle alone; no measured fp32 error enters it.
-    Returns (tol_xy [F, J], tol_z [F, J] or None)."""
+    The joint confidence (max of 2x2 window sums of the PROBABILITY maps, layers.py:107-119) moves by at most
+    2 e relative (p_i = exp(l_i) / sum_j exp(l_j)), hence tol_c = max(2e-6, 2 * e * c).
+    Returns (tol_xy [F, J], tol_z [F, J] or None, tol_c [F, J])."""
     import torch
     from oracle import ops
     l = torch.from_numpy(np.asarray(logits64, dtype=np.float64))
@@ -73,23 +75,28 @@ def conditioned_tolerance(logits64, dlogits64=None):
         sz = (p * np.abs(sg - z[:, None, None, :])).sum(axis=(1, 2))
         e_d = ULP_BUDGET * ulp(dlogits64)
         tol_z = np.minimum(PX_CAP, np.maximum(PX_TOL, sz * e_h + 0.25 * e_d))      # sigmoid' <= 1/4
-    return tol_xy, tol_z
+    conf = ops.joints_probability(torch.from_numpy(p)).numpy()[..., 0]
+    tol_c = np.maximum(2e-6, 2.0 * e_h * conf)
+    return tol_xy, tol_z, tol_c
 
 
-def check_conditioned(name, hip, o32, o64, tol_arr, case=None):
+def check_conditioned(name, hip, o32, o64, tol_arr, case=None, px=True):
     """Like check(), with a per-element tolerance array broadcast over the last axis (coordinates)."""
     hip, o32, o64 = (np.asarray(v, dtype=np.float64) for v in (hip, o32, o64))
     t = tol_arr.reshape(hip.shape[:tol_arr.ndim] + (1,) * (hip.ndim - tol_arr.ndim)) if hip.ndim > tol_arr.ndim \
         else tol_arr.reshape(hip.shape)
     d = np.abs(hip - o64)
-    strict = float(np.mean(tol_arr <= PX_TOL * (1 + 1e-12)))
-    RECORDS.append(dict(case=case or os.environ.get('PYTEST_CURRENT_TEST', '').split(' ')[0], output=name, unit='px',
-                        tol=256 * PX_TOL, tol_max=256 * float(tol_arr.max()), strict_fraction=strict,
-                        hip_vs_o64=256 * float(d.max()), o32_vs_o64=256 * float(np.abs(o32 - o64).max()),
-                        hip_vs_o32=256 * float(np.abs(hip - o32).max()),
+    base = float(tol_arr.min()) if not px else PX_TOL
+    strict = float(np.mean(tol_arr <= base * (1 + 1e-12)))
+    k = 256.0 if px else 1.0
+    RECORDS.append(dict(case=case or os.environ.get('PYTEST_CURRENT_TEST', '').split(' ')[0], output=name,
+                        unit='px' if px else 'abs', tol=k * base, tol_max=k * float(tol_arr.max()),
+                        strict_fraction=strict, hip_vs_o64=k * float(d.max()),
+                        o32_vs_o64=k * float(np.abs(o32 - o64).max()), hip_vs_o32=k * float(np.abs(hip - o32).max()),
                         worst_ratio_to_tol=float((d / t).max()), n=int(hip.size)))
-    print('%-14s hip-o64=%.3e  o32-o64=%.3e px  worst |d|/tol=%.2f  joints at 1e-3 px: %.0f %%  (loosest %.2e px)' % (
-        name, 256 * d.max(), 256 * np.abs(o32 - o64).max(), (d / t).max(), 100 * strict, 256 * tol_arr.max()))
+    print('%-14s hip-o64=%.3e  o32-o64=%.3e %s  worst |d|/tol=%.2f  at the base tolerance: %.0f %%  (loosest %.2e)' % (
+        name, k * d.max(), k * np.abs(o32 - o64).max(), 'px' if px else '', (d / t).max(), 100 * strict,
+        k * tol_arr.max()))
     assert np.all(d <= t), '%s: HIP differs from the fp64 oracle by up to %.2f x the conditioned tolerance' % (
         name, (d / t).max())
 

@@ -241,13 +241,13 @@ def spnet_parity(m, cfg, wd, ocfg, x, pyr, apyr, case=None):
     for k, b in enumerate(blocks):
         std = float(t64[b + '/logits'].std())
         assert 1.0 < std < 30.0, 'heat-map logits of %s are flat or one-hot (std %.2f): vacuous test' % (b, std)
-        tol_xy, tol_z = paritylog.conditioned_tolerance(t64[b + '/logits'], t64.get(b + '/dlogits'))
+        tol_xy, tol_z, tol_c = paritylog.conditioned_tolerance(t64[b + '/logits'], t64.get(b + '/dlogits'))
         flat = lambda a: a.reshape((-1,) + a.shape[-2:])
         h, a32, a64 = flat(hip[k]), flat(o32[k]), flat(o64[k])
         paritylog.check_conditioned('%s.xy' % b, h[..., :2], a32[..., :2], a64[..., :2], tol_xy, case=case)
         if dim == 3:
             paritylog.check_conditioned('%s.z' % b, h[..., 2], a32[..., 2], a64[..., 2], tol_z, case=case)
-        _check('%s.conf' % b, h[..., dim], a32[..., dim], a64[..., dim], 2e-6, case=case)
+        paritylog.check_conditioned('%s.conf' % b, h[..., dim], a32[..., dim], a64[..., dim], tol_c, case=case, px=False)
     for k in range(npose, npose + nact_out):
         _check('action%d' % (k - npose), hip[k], o32[k], o64[k], 1e-5, case=case)
         assert np.array_equal(hip[k].argmax(-1), o64[k].argmax(-1))
@@ -372,11 +372,12 @@ def test_hip_matches_reference_code_goldens(tag, hip_lib, cuda):
         elif tols is not None:
             flat = lambda v: v.reshape((-1,) + v.shape[-2:])
             dim = b.shape[-1] - 1
-            txy, tz = tols[k]
+            txy, tz, tc = tols[k]
             paritylog.check_conditioned('%s.out%d.xy' % (tag, k), flat(h)[..., :2], flat(a)[..., :2], flat(b)[..., :2], txy)
             if dim == 3:
                 paritylog.check_conditioned('%s.out%d.z' % (tag, k), flat(h)[..., 2], flat(a)[..., 2], flat(b)[..., 2], tz)
-            _check('%s.out%d.c' % (tag, k), h[..., dim], a[..., dim], b[..., dim], 2e-6)
+            paritylog.check_conditioned('%s.out%d.c' % (tag, k), flat(h)[..., dim], flat(a)[..., dim], flat(b)[..., dim], tc,
+                                        px=False)
         else:
             _check('%s.out%d' % (tag, k), h, a, b, PX_TOL if b.shape[-1] != 1 else 1e-5, rel=(b.shape[-1] == 1))
 

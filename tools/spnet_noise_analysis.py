@@ -46,12 +46,7 @@ def sensitivity(p64, xy64):
     return float(max(sx.max(), sy.max()))
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument('--frames', type=int, default=4)
-    ap.add_argument('--out', default=None)
-    ap.add_argument('--no-hip', action='store_true')
-    a = ap.parse_args()
+def analyse(a, calibrate):
     from deephar_amd import graph, weights, utils, Model
     from deephar_amd.config import ModelConfig
     from deephar_amd.models import spnet
@@ -68,10 +63,15 @@ def main():
                 num_levels=4, kernel_size=(5, 5), growth=96, image_div=8, num_pose_features=192,
                 num_visual_features=192, sam_alpha=1)
     x = np.random.default_rng(11).uniform(-1, 1, (1, T, 256, 256, 3)).astype(np.float32)
+    if calibrate:
+        sys.path.insert(0, os.path.join(ROOT, 'tests'))
+        import paritylog
+        paritylog.calibrate_spnet_heads(m, ocfg, x)
+        wd = weights.as_dict(m)
     t32, t64 = {}, {}
     o32 = osp.forward(wd, x, ocfg, dtype=torch.float32, taps=t32)
     o64 = osp.forward(wd, x, ocfg, dtype=torch.float64, taps=t64)
-    blocks = [k[:-len('/logits')] for k in t64]
+    blocks = [k[:-len('/logits')] for k in t64 if k.endswith('/logits')]
     npose = len(blocks)
 
     hip_logits, hip_out = None, None
@@ -110,11 +110,25 @@ def main():
                 first_order_bound_px=256 * float(np.abs(lg - l64).max()) * row['sensitivity'])
         rows.append(row)
         print(json.dumps(row))
+    return rows
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--frames', type=int, default=4)
+    ap.add_argument('--out', default=None)
+    ap.add_argument('--no-hip', action='store_true')
+    a = ap.parse_args()
+    T = a.frames
+    print('--- heads as init_synthetic leaves them')
+    rows = analyse(a, False)
+    print('--- heads calibrated to logit std 6 (tests/paritylog.py: calibrate_spnet_heads)')
+    rows_cal = analyse(a, True)
     out = a.out or os.path.join(ROOT, 'gpurun_out' if torch.cuda.is_available() else 'profiles', 'r02_spnet_noise.json')
     os.makedirs(os.path.dirname(out), exist_ok=True)
     with open(out, 'w') as fh:
         json.dump(dict(config='SPNet NTU-like (pa17j3d, 2 pyramids, actions on 1,2), T=%d frames, 256x256, seed 0/11' % T,
-                       tolerance_px=1e-3, blocks=rows), fh, indent=1)
+                       tolerance_px=1e-3, blocks=rows, blocks_calibrated=rows_cal), fh, indent=1)
     print('wrote', out)
 
 
