@@ -21,6 +21,10 @@ class ConvArgs(C.Structure):
                                    'up2', 'x_u8')]
 
 
+class SepConvArgs(C.Structure):
+    _fields_ = [('pw', ConvArgs), ('dw_w', vp)] + [(n, i32) for n in ('DKH', 'DKW', 'DPT', 'DPL')]
+
+
 class DwArgs(C.Structure):
     _fields_ = [(n, vp) for n in ('x', 'w', 'y', 'pre_scale', 'pre_shift')] + \
                [(n, i32) for n in ('N', 'H', 'W', 'C', 'ldx', 'ldy', 'KH', 'KW', 'PT', 'PL', 'pre_relu')]
@@ -54,6 +58,8 @@ SIGNATURES = {
     'dh_conv2d_num_tile_cfgs': (C.c_int, []),
     'dh_conv2d_pick_tile_cfg': (C.c_int, [C.c_int, C.c_int]),
     'dh_conv2d_f32': (C.c_int, [C.POINTER(ConvArgs), C.c_int, vp]),
+    'dh_sepconv2d_num_tile_cfgs': (C.c_int, []),
+    'dh_sepconv2d_f32': (C.c_int, [C.POINTER(SepConvArgs), C.c_int, vp]),
     'dh_normalize_u8_f32': (C.c_int, [vp, vp, vp, C.c_int64, C.c_int, vp]),
     'dh_dwconv2d_f32': (C.c_int, [C.POINTER(DwArgs), vp]),
     'dh_pool2d_f32': (C.c_int, [C.POINTER(PoolArgs), vp]),

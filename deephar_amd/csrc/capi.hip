@@ -79,6 +79,17 @@ int dh_dwconv2d_f32(const dh_dw_args* a, void* stream) {
   return launch_dwconv(*a, S(stream));
 }
 
+int dh_sepconv2d_num_tile_cfgs(void) { return sepconv_num_cfgs(); }
+
+int dh_sepconv2d_f32(const dh_sepconv_args* a, int tile_cfg, void* stream) {
+  if (a == nullptr || a->pw.x == nullptr || a->pw.w == nullptr || a->pw.y == nullptr || a->dw_w == nullptr)
+    return DH_EINVAL;
+  if ((a->pw.post_scale == nullptr) != (a->pw.post_shift == nullptr)) return DH_EINVAL;
+  if (a->pw.Kp % 32 != 0 || a->pw.Np % 32 != 0 || a->pw.Kp < a->pw.K || a->pw.Np < a->pw.Cout) return DH_EINVAL;
+  if (tile_cfg >= sepconv_num_cfgs()) return DH_EINVAL;
+  return launch_sepconv_fused(a->pw, a->dw_w, a->DKH, a->DKW, a->DPT, a->DPL, tile_cfg, S(stream));
+}
+
 int dh_pool2d_f32(const dh_pool_args* a, void* stream) {
   if (a == nullptr || a->x == nullptr || a->y == nullptr || a->SH <= 0 || a->SW <= 0) return DH_EINVAL;
   return launch_pool(*a, S(stream));

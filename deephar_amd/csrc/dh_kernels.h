@@ -18,6 +18,9 @@ int launch_normalize_u8(const unsigned char* x, const float* lut, float* y, long
 int conv_igemm_pick_cfg(int M, int Cout);
 int conv_igemm_num_cfgs();
 int launch_dwconv(const DwArgs& a, hipStream_t s);
+int sepconv_num_cfgs();
+int launch_sepconv_fused(const ConvArgs& pw, const float* dw, int dkh, int dkw, int dpt, int dpl, int cfg,
+                         hipStream_t s);
 int launch_pool(const PoolArgs& a, hipStream_t s);
 int launch_upsample2x_add(const float* a, int lda, const float* b, int ldb, float* y, int ldy, int N, int H,
                           int W, int C, hipStream_t s);

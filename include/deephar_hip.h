@@ -101,6 +101,27 @@ typedef struct dh_dw_args {
 } dh_dw_args;
 int dh_dwconv2d_f32(const dh_dw_args* a, void* stream);
 
+/* ---------------------------------------------------------------------------------------------------
+ * keras SeparableConv2D in ONE launch (layers.sepconv2d, layers.py:74-80; separable_act_conv_bn :288-301;
+ * reception._sepconv_residual, reception.py:43-59; common.residual_unit's 'depthwise' branch, common.py:47-48):
+ * the depthwise K x K (K in {3, 5}, stride 1, TF-SAME, depth_multiplier 1) is evaluated on the fly as the A operand
+ * of the pointwise GEMM, so the depthwise tensor never reaches HBM.
+ *   `pw`  describes the POINTWISE convolution exactly as for dh_conv2d_f32 (KH = KW = 1, SH = SW = 1, no padding,
+ *         K = Cin, packed weight, epilogue fields, up2) with x / H / W / Cin / ldx = the input of the depthwise
+ *         stage; pw.pre_relu is applied to that input (ReLU -> depthwise -> pointwise); pw.pre_scale must be NULL.
+ *   `dw_w` [DKH*DKW][Cin] depthwise taps (= Keras [KH,KW,C,1]), (DPT, DPL) = explicit top / left padding.
+ * Results are bit-identical to dh_dwconv2d_f32 followed by dh_conv2d_f32 (same tap order, same K order).
+ * Returns DH_EUNSUPPORTED for shapes outside the fused kernel (callers fall back to the pair).
+ * tile_cfg < 0: library heuristic; 0..dh_sepconv2d_num_tile_cfgs()-1 forces a tiling (autotuning hook).
+ * ------------------------------------------------------------------------------------------------- */
+typedef struct dh_sepconv_args {
+  dh_conv_args pw;
+  const float* dw_w;
+  int32_t DKH, DKW, DPT, DPL;
+} dh_sepconv_args;
+int dh_sepconv2d_num_tile_cfgs(void);
+int dh_sepconv2d_f32(const dh_sepconv_args* a, int tile_cfg, void* stream);
+
 /* MaxPooling2D (reception.py:74,86,108,115; layers.py:92-97), padding cells ignored;
  * mode 1 = layers.max_min_pooling (layers.py:411-425): maxpool(x) - maxpool(-x) */
 typedef struct dh_pool_args {

@@ -333,3 +333,93 @@ def test_kxk_conv_on_the_dma_kernel(case, cfg, hip_lib, cuda):
     ref = O.conv2d(O.relu(torch.from_numpy(x).double()), torch.from_numpy(k).double(), (s, s), pad)
     ref = torch.relu(ref * torch.from_numpy(qs).double() + torch.from_numpy(qb).double() + torch.from_numpy(r1).double())
     _close(a, ref, atol=5e-5, what='kxk dma conv')
+
+
+# ---- fused SeparableConv2D (dh_sepconv2d_f32) ----------------------------------------------------------------------
+SEP_CASES = [
+    # (N, H, W, Cin, Cout, K, residual, up2)  -- the separable convs of the models
+    (2, 32, 32, 576, 576, 5, True, False),      # _sepconv_residual at 32x32 (reception.py:43-59), 46 % of the MACs
+    (1, 32, 32, 576, 576, 5, False, False),     # SepConv%d (reception.py:134-142)
+    (2, 32, 32, 384, 576, 3, True, False),      # stem's 3x3 separable conv (reception.py:92-93)
+    (3, 16, 16, 288, 288, 5, True, False),
+    (3, 8, 8, 288, 288, 5, True, False),        # two whole frames per 128-row tile
+    (2, 16, 16, 288, 576, 5, True, True),       # hourglass merge: conv -> UpSampling2D -> add (reception.py:122-127)
+    (1, 8, 8, 288, 288, 5, True, True),         # M = 64 < one tile
+    (5, 4, 4, 576, 576, 5, True, False),        # SPNet 4x4 level, 5 frames = ragged tile
+    (2, 16, 16, 384, 384, 5, False, False),     # SPNet level widths
+    (2, 8, 8, 480, 480, 5, False, False),
+    (1, 32, 32, 32, 40, 3, False, False),       # tiny K, ragged Cout
+]
+
+
+def _sep_inputs(case, cuda, seed=0):
+    n, h, w, cin, cout, ks, res, up2 = case
+    rng = np.random.default_rng(seed + sum(int(v) for v in case))
+    x = _rand(rng, (n, h, w, cin))
+    dw = _rand(rng, (ks, ks, cin, 1), np.sqrt(2.0 / (ks * ks)))
+    pw = _rand(rng, (1, 1, cin, cout), np.sqrt(1.0 / cin))
+    sc = rng.uniform(0.5, 1.5, cout).astype(np.float32)
+    sh = _rand(rng, (cout,), 0.1)
+    r1 = _rand(rng, (n, h, w, cout)) if res else None
+    r2 = _rand(rng, (n, 2 * h, 2 * w, cout)) if up2 else None
+    d = lambda a: None if a is None else torch.from_numpy(a).to(cuda)
+    return x, dw, pw, sc, sh, r1, r2, d
+
+
+@pytest.mark.parametrize('case', SEP_CASES)
+def test_sepconv_fused_equals_unfused_pair_bitwise(case, hip_lib, cuda):
+    """The fused kernel sums the depthwise taps and the pointwise K in the order of dh_dwconv2d_f32 + dh_conv2d_f32:
+    every tiling must reproduce the two-launch result bit for bit, for ReLU / no ReLU on the input."""
+    from deephar_amd import functional as F
+    from deephar_amd._lib import DeepharHipError
+    x, dw, pw, sc, sh, r1, r2, d = _sep_inputs(case, cuda)
+    up2 = case[7]
+    ran = 0
+    for pre_relu in (True, False):
+        mid = F.dwconv2d(d(x), dw, pre_relu=pre_relu)
+        ref = F.conv2d(mid, pw, post_scale=d(sc), post_shift=d(sh), res1=d(r1), res2=d(r2), up2=up2)
+        torch.cuda.synchronize()
+        for cfg in range(-1, hip_lib.dh_sepconv2d_num_tile_cfgs()):
+            try:
+                got = F.sepconv2d(d(x), dw, pw, pre_relu=pre_relu, post_scale=d(sc), post_shift=d(sh), res1=d(r1),
+                                  res2=d(r2), up2=up2, tile_cfg=cfg)
+            except DeepharHipError as e:
+                assert 'rc=-2' in str(e), e          # a tiling that cannot hold this map: allowed, but not for all
+                continue
+            torch.cuda.synchronize()
+            ran += 1
+            assert torch.equal(got, ref), 'case %s cfg %d relu %s: max |d| = %.3e' % (
+                case, cfg, pre_relu, (got - ref).abs().max().item())
+    assert ran >= 2, 'no fused tiling ran for %s' % (case,)
+
+
+@pytest.mark.parametrize('case', SEP_CASES[:7])
+def test_sepconv_fused_vs_oracle(case, hip_lib, cuda):
+    """... and against the CPU oracle's SeparableConv2D (oracle/ops.py sepconv2d = F.conv2d depthwise + 1x1)."""
+    from deephar_amd import functional as F
+    x, dw, pw, sc, sh, r1, r2, d = _sep_inputs(case, cuda, seed=1)
+    up2 = case[7]
+    t = torch.from_numpy
+    ref = O.sepconv2d(O.relu(t(x)), t(dw), t(pw)) * t(sc) + t(sh)
+    if r1 is not None:
+        ref = ref + t(r1)
+    if up2:
+        ref = O.upsample2d(ref) + t(r2)
+    got = F.sepconv2d(d(x), dw, pw, pre_relu=True, post_scale=d(sc), post_shift=d(sh), res1=d(r1), res2=d(r2), up2=up2)
+    torch.cuda.synchronize()
+    _close(got, ref, atol=1e-4, rtol=1e-4, what='sepconv %s' % (case,))
+
+
+def test_sepconv_fused_frames_do_not_leak(hip_lib, cuda):
+    """Tiles that span several small frames (8x8: two frames per 128-row tile) must treat the rows of the neighbouring
+    frame as zero padding: changing frame 1 must not change a bit of frame 0."""
+    from deephar_amd import functional as F
+    case = (4, 8, 8, 288, 288, 5, False, False)
+    x, dw, pw, sc, sh, _, _, d = _sep_inputs(case, cuda)
+    a = F.sepconv2d(d(x), dw, pw, pre_relu=True)
+    x2 = x.copy()
+    x2[1] = 7.0
+    x2[3] = -3.0
+    b = F.sepconv2d(d(x2), dw, pw, pre_relu=True)
+    torch.cuda.synchronize()
+    assert torch.equal(a[0], b[0]) and torch.equal(a[2], b[2]) and not torch.equal(a[1], b[1])

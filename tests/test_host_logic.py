@@ -28,7 +28,7 @@ def test_ctypes_structs_match_header_layout(hip_lib, tmp_path):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     header = open(os.path.join(root, 'include', 'deephar_hip.h')).read()
     pairs = {'dh_conv_args': _lib.ConvArgs, 'dh_dw_args': _lib.DwArgs, 'dh_pool_args': _lib.PoolArgs,
-             'dh_elt_args': _lib.EltArgs, 'dh_sam_args': _lib.SamArgs}
+             'dh_elt_args': _lib.EltArgs, 'dh_sam_args': _lib.SamArgs, 'dh_sepconv_args': _lib.SepConvArgs}
     structs = set(re.findall(r'typedef struct (dh_\w+_args)', header))
     assert structs == set(pairs), structs ^ set(pairs)
     lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "deephar_hip.h"', 'int main(void) {']
