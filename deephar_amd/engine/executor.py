@@ -201,10 +201,11 @@ class BoundPlan:
             v = d.get(role)
             return P(v) if v is not None else None
 
-        if k == 'conv':
+        if k in ('conv', 'sepconv'):
             x, y = s.ins['x'], s.outs['y']
             wt, kp, np_ = self.store.conv_weight(s.params['w'])
-            args = _lib.ConvArgs()
+            sep = _lib.SepConvArgs() if k == 'sepconv' else None
+            args = sep.pw if sep is not None else _lib.ConvArgs()
             args.x, args.w, args.y = P(x), wt.data_ptr(), P(y)
             if 'pre_bn' in s.params:
                 sc, sh = self.store.bn_affine(s.params['pre_bn'])
@@ -227,8 +228,14 @@ class BoundPlan:
             if self.u8 is not None and id(x.buf) in self.u8 and self.u8[id(x.buf)][2]:
                 buf, lut, _ = self.u8[id(x.buf)]
                 args.x, args.in_lut, args.x_u8 = buf.data_ptr(), lut.data_ptr(), 1
-            self._keep.append(args)
-            self.calls.append((lib.dh_conv2d_f32, (C.byref(args), a.get('tile_cfg', -1)), s))
+            if sep is not None:
+                sep.dw_w = self.store.dw_weight(s.params['dw']).data_ptr()
+                sep.DKH, sep.DKW, sep.DPT, sep.DPL = a['dkh'], a['dkw'], a['dpt'], a['dpl']
+                self._keep.append(sep)
+                self.calls.append((lib.dh_sepconv2d_f32, (C.byref(sep), a.get('tile_cfg', -1)), s))
+            else:
+                self._keep.append(args)
+                self.calls.append((lib.dh_conv2d_f32, (C.byref(args), a.get('tile_cfg', -1)), s))
         elif k == 'dwconv':
             x, y = s.ins['x'], s.outs['y']
             args = _lib.DwArgs()
@@ -428,9 +435,14 @@ class BoundPlan:
     @staticmethod
     def _conv_signature(step):
         a, x, y = step.attrs, step.ins['x'], step.outs['y']
+        r1, r2 = step.ins.get('res1'), step.ins.get('res2')
+        # the 16-byte alignment of every view decides which kernels / epilogues are eligible (gemm1x1_eligible, the
+        # vector epilogue), so it is part of the identity of a tuned shape -- as are padding and the output size
+        align = (x.coff % 4, y.coff % 4, r1.coff % 4 if r1 is not None else 0, r2.coff % 4 if r2 is not None else 0,
+                 r1.ld % 4 if r1 is not None else 0, r2.ld % 4 if r2 is not None else 0)
         return (x.lead(3), x.shape[-3], x.shape[-2], x.C, x.ld, y.ld, a['Cout'], a['kh'], a['kw'], a['sh'],
                 a['sw'], a['pre_relu'], a['post_relu'], a['up2'], 'res1' in step.ins, 'res2' in step.ins,
-                'pre_bn' in step.params, 'post_bn' in step.params)
+                'pre_bn' in step.params, 'post_bn' in step.params, a['pt'], a['pl'], y.shape[-3], y.shape[-2]) + align
 
     def autotune(self, stream_ptr, table=None, reps=3):
         """Time every tile configuration of dh_conv2d_f32 for each distinct conv shape of this bound plan
@@ -438,14 +450,16 @@ class BoundPlan:
         so the choice never changes a result bit.  `table` (signature -> cfg) is filled / reused."""
         lib = self.lib
         table = {} if table is None else table
-        ncfg = lib.dh_conv2d_num_tile_cfgs()
+        ncfgs = {'conv': lib.dh_conv2d_num_tile_cfgs(), 'sepconv': lib.dh_sepconv2d_num_tile_cfgs()}
         e0, e1 = C.c_void_p(), C.c_void_p()
         _lib.check(lib.dh_event_create(C.byref(e0)))
         _lib.check(lib.dh_event_create(C.byref(e1)))
         for i, (fn, args, step) in enumerate(self.calls):
-            if step.kind != 'conv':
+            if step.kind not in ncfgs:
                 continue
-            sig = (self.n,) + self._conv_signature(step) + ((('u8',) if args[0]._obj.x_u8 else ()))
+            ncfg = ncfgs[step.kind]
+            cargs = args[0]._obj.pw if step.kind == 'sepconv' else args[0]._obj
+            sig = (self.n, step.kind) + self._conv_signature(step) + ((('u8',) if cargs.x_u8 else ()))
             if sig not in table:
                 best, best_ms = -1, float('inf')
                 for cfg in range(ncfg):
@@ -532,7 +546,8 @@ class Executor:
         self.autotune = autotune
         self.tune_table = {}
         self.store = WeightStore(self.device)
-        self.bound = {}
+        self.bound = {}            # key -> BoundPlan, most recently used last; at most `max_bound` are kept
+        self.max_bound = max(1, int(os.environ.get('DEEPHAR_MAX_BOUND_PLANS', '4')))
         self._wstamp = None        # sum of Param.version over plan.params at the last refresh / first bind
         with torch.cuda.device(self.device):
             self.stream = torch.cuda.Stream(device=self.device)
@@ -553,6 +568,13 @@ class Executor:
                 if self.autotune:
                     bp.autotune(self.stream_ptr, self.tune_table)
             self.bound[key] = bp
+            while len(self.bound) > self.max_bound:         # dataset tails / box-refinement loops bind many sizes:
+                old = next(iter(self.bound))                # drop the least recently used arena + graph
+                if old == key:
+                    break
+                del self.bound[old]
+        else:
+            self.bound[key] = self.bound.pop(key)           # mark as most recently used
         return bp
 
     def _weight_stamp(self):
@@ -578,6 +600,8 @@ class Executor:
                 for role, p in s.params.items():
                     if role == 'w':
                         (self.store.dw_weight if s.kind == 'dwconv' else self.store.conv_weight)(p)
+                    elif role == 'dw':
+                        self.store.dw_weight(p)
                     else:
                         self.store.bn_affine(p)
         self.stream.synchronize()

@@ -13,6 +13,8 @@ Fusion rules (what the reference leaves to TensorFlow as separate kernels):
                 resolution; a free-standing UpSampling2D -> add becomes one upsample_add kernel.
   R4 concat   : producers write straight into the concatenation buffer at their channel offset
                 (reception.py:75,83,87); Lambda channel slices are pointer/ld views (reception.py:171-172).
+  R6 sepconv  : (optional, DEEPHAR_FUSE_SEPCONV=1) ReLU -> depthwise -> pointwise -> epilogue as one launch
+                (layers.py:74-80, 288-301); off by default, see Planner.__init__.
   R5 decoder  : channel soft-max + both lin_interpolation_2d + joint confidence (+ global max) on the same
                 maps are one soft-argmax kernel (blocks.py:306-343).
 All tensors are fp32; sizes are tracked per batch item so one plan serves any batch size.
@@ -71,10 +73,11 @@ class Step:
     def flops(self, n=1):
         """Algorithmic FLOPs (2*MAC) for n batch items (conv/GEMM-shaped steps only)."""
         a = self.attrs
-        if self.kind == 'conv':
+        if self.kind in ('conv', 'sepconv'):
             y = self.outs['y']
             m = y.npix // (4 if a.get('up2') else 1)
-            return 2.0 * n * m * a['K'] * a['Cout']
+            dw = 2.0 * n * m * a['Cin'] * a['dkh'] * a['dkw'] if self.kind == 'sepconv' else 0.0
+            return 2.0 * n * m * a['K'] * a['Cout'] + dw
         if self.kind == 'dwconv':
             y = self.outs['y']
             return 2.0 * n * y.npix * y.C * a['kh'] * a['kw']
@@ -116,9 +119,18 @@ class _Lazy:
         self.relu = relu
 
 
+def _fuse_sepconv_default():
+    import os
+    return os.environ.get('DEEPHAR_FUSE_SEPCONV', '0') == '1'
+
+
 class Planner:
-    def __init__(self, inputs, outputs, nstreams=1):
+    def __init__(self, inputs, outputs, nstreams=1, fuse_sepconv=None):
         self.nstreams = nstreams
+        # R6 (optional): SeparableConv2D as ONE launch (dh_sepconv2d_f32, depthwise evaluated as the A operand of the
+        # pointwise GEMM).  Bit-identical to the two-launch pair but measured 7-40 % SLOWER on gfx950: the fp32 MFMA
+        # leaves no issue slots for the depthwise stage (profiles/r02_sepconv_fusion_study.md), so it is off by default.
+        self.fuse_sepconv = _fuse_sepconv_default() if fuse_sepconv is None else bool(fuse_sepconv)
         self.g_inputs = inputs
         self.g_outputs = outputs
         self.nodes = G.topo_nodes(outputs)
@@ -287,7 +299,8 @@ class Planner:
                             t = a.outputs[0]
         return epi, t
 
-    def _emit_conv(self, x, pre_bn, pre_relu, param, a, out_t, name):
+    def _emit_conv(self, x, pre_bn, pre_relu, param, a, out_t, name, dw=None):
+        """dw = (depthwise Param, node attrs): emit the fused separable step (kind 'sepconv') instead of a conv."""
         epi, final_t = self._epilogue(out_t)
         y = self.out_value_for(final_t)
         attrs = dict(kh=a['kh'], kw=a['kw'], sh=a.get('sh', 1), sw=a.get('sw', 1), pt=a['pt'], pl=a['pl'],
@@ -303,7 +316,10 @@ class Planner:
             params['pre_bn'] = pre_bn
         if epi['post_bn'] is not None:
             params['post_bn'] = epi['post_bn']
-        self.emit('conv', ins, dict(y=y), attrs, params, name)
+        if dw is not None:
+            params['dw'] = dw[0]
+            attrs.update(dkh=dw[1]['kh'], dkw=dw[1]['kw'], dpt=dw[1]['pt'], dpl=dw[1]['pl'])
+        self.emit('sepconv' if dw is not None else 'conv', ins, dict(y=y), attrs, params, name)
         self.val[final_t.uid] = y
 
     def op_conv(self, node):
@@ -315,6 +331,13 @@ class Planner:
         x, pre_bn, pre_relu = self._prologue(node.inputs[0])
         layer = node.layers['sepconv']
         a = node.attrs
+        pw = dict(kh=1, kw=1, sh=1, sw=1, pt=0, pl=0, filters=a['filters'])
+        h, w = node.inputs[0].shape[-3], node.inputs[0].shape[-2]
+        if self.fuse_sepconv and pre_bn is None and a['kh'] == a['kw'] and a['kh'] in (3, 5) and \
+                a['pt'] == (a['kh'] - 1) // 2 and a['pl'] == a['pt'] and x.C % 16 == 0 and x.ld % 4 == 0 and \
+                x.coff % 4 == 0 and h % 2 == 0 and w <= 32 and 128 % (2 * w) == 0:
+            self._emit_conv(x, None, pre_relu, layer.params[1], pw, node.outputs[0], node.name, dw=(layer.params[0], a))
+            return
         mid = self.new_value(node.inputs[0].shape)
         params = dict(w=layer.params[0])
         if pre_bn is not None:
@@ -322,7 +345,6 @@ class Planner:
         self.emit('dwconv', dict(x=x), dict(y=mid),
                   dict(kh=a['kh'], kw=a['kw'], pt=a['pt'], pl=a['pl'], pre_relu=int(pre_relu)), params,
                   node.name + '/dw')
-        pw = dict(kh=1, kw=1, sh=1, sw=1, pt=0, pl=0, filters=a['filters'])
         self._emit_conv(mid, None, False, layer.params[1], pw, node.outputs[0], node.name + '/pw')
 
     # ---- glue ------------------------------------------------------------------------------------------
@@ -581,5 +603,5 @@ class Planner:
         self.plan.params = out
 
 
-def build_plan(inputs, outputs, nstreams=1):
-    return Planner(inputs, outputs, nstreams).run()
+def build_plan(inputs, outputs, nstreams=1, fuse_sepconv=None):
+    return Planner(inputs, outputs, nstreams, fuse_sepconv).run()

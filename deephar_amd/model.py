@@ -41,6 +41,7 @@ class Model:
         # uint8 inputs are raw frames: predict() normalises them on the GPU exactly like the reference's loaders do
         # on the host (utils/transform.normalize_channels(frame, channel_power), transform.py:212-231)
         self.channel_power = 1
+        self.fuse_sepconv = None      # None: DEEPHAR_FUSE_SEPCONV (default off); see engine/planner.py R6
         # validates connectivity early (raises like Keras' "graph disconnected")
         self._nodes = G.topo_nodes(self.outputs)
         reach = {t.uid for t in self.inputs}
@@ -168,7 +169,8 @@ class Model:
     def plan(self):
         if self._plan is None:
             from .engine.planner import build_plan
-            self._plan = build_plan(self.inputs, self.outputs, nstreams=self.num_streams)
+            self._plan = build_plan(self.inputs, self.outputs, nstreams=self.num_streams,
+                                    fuse_sepconv=self.fuse_sepconv)
         return self._plan
 
     @property

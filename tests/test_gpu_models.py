@@ -450,3 +450,22 @@ def test_hip_matches_real_keras_outputs(tag, hip_lib, cuda):
             np.testing.assert_allclose(h, r, rtol=1e-3, atol=1e-4)
         else:                                             # two fp32 implementations: a few times 1e-3 px is fp32 noise
             assert float(np.max(np.abs(h - r))) <= 4 * PX_TOL, (tag, k)
+
+
+def test_fused_sepconv_plan_is_bit_identical(hip_lib, cuda):
+    """Planner rule R6 (DEEPHAR_FUSE_SEPCONV=1 / Model.fuse_sepconv): every SeparableConv2D as one dh_sepconv2d_f32
+    launch.  Same taps order, same K order -> the model's outputs do not change by a bit (it is off by default only
+    because it is slower on gfx950: profiles/r02_sepconv_fusion_study.md)."""
+    from collections import Counter
+    x = np.random.default_rng(9).uniform(-1, 1, (3, 256, 256, 3)).astype(np.float32)
+    m, _ = _build(2, 2, 16, num_context_per_joint=2)
+    m.fuse_sepconv = False
+    ref = m.predict(x, batch_size=3)
+    assert Counter(s.kind for s in m.plan.steps)['dwconv'] == 17
+    f, _ = _build(2, 2, 16, num_context_per_joint=2)
+    f.fuse_sepconv = True
+    kinds = Counter(s.kind for s in f.plan.steps)
+    assert kinds['sepconv'] == 17 and kinds['dwconv'] == 0
+    got = f.predict(x, batch_size=3)
+    for a, b in zip(ref, got):
+        assert np.array_equal(a, b)
