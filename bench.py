@@ -1,20 +1,33 @@
 #!/usr/bin/env python
-"""Headline benchmark: frames/s of the 256x256 MPII pose forward (BASELINE.json configs[1]).
+"""Headline benchmark of the pose-regression hot path on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W [--workload mpii|penn_merge|ntu_spnet]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 
-One "step" = one forward pass of ReceptionNet (8 blocks, J=16, 2 contexts, 5x5) over one batch of 64
-synthetic 256x256x3 frames per GPU, inputs already resident in HBM, all outputs (8 x [pose, visible]) left in
-HBM.  Frames shard embarrassingly over ranks (weak scaling, no data-path collective for the pose-only path);
-value = frames all ranks processed / max-over-ranks wall time of exactly K steps bracketed by barriers +
-device synchronisation.  Rank 0 prints ONE JSON line, which also carries
-  roofline     : the dominant kernel (MFMA implicit-GEMM conv) -- algorithmic FLOPs of all its launches in one
-                 step / their summed duration, measured with HIP events recorded on the launch stream in a
-                 separate eager pass right after the timed region (kernels inside a replayed hipGraph cannot
-                 be bracketed by events); peak = 157.3 TFLOP/s fp32 MFMA (MI355X_MICROARCH.md).
-  cpu_baseline : the CPU oracle (a port; TensorFlow/Keras are not installable here) timed on the host cores
-                 of this box on a bounded sample of the same workload.  N=1, rank 0 only.
+Workloads (BASELINE.json `configs`):
+  mpii        (default; configs[1], the configuration `metric` is quoted on) ReceptionNet 8 blocks, J=16, 2 contexts,
+              5x5: one step = one forward over a batch of 64 synthetic 256x256x3 frames per GPU.  Frames shard over
+              ranks with no data-path collective (weak scaling).
+  penn_merge  (configs[3]) merge model, 16-frame clips, 4 blocks, 15 actions, 4 clips per GPU and step;
+  ntu_spnet   (configs[4]) SPNet pa17j3d, 60 actions, 32-frame clips, 8 clips per GPU and step.
+              Clip workloads are FRAME-SHARDED: every rank runs T/N frames of all N x clips_per_gpu clips through the
+              frame stage (conv stack + decoder + kronecker pooling), ONE RCCL all-gather of the packed
+              [clips, T/N, J, C] tensor, then the (tiny) action head replicated on every rank -- all device resident
+              (deephar_amd/parallel.py).  `collective_us` is the all-gather's share of a step (HIP events).
+One step is timed with the inputs already resident in HBM and the outputs left in HBM: value = frames all ranks
+processed / max-over-ranks wall time of exactly K steps bracketed by barriers + device synchronisation.
+Rank 0 prints ONE JSON line, which also carries
+  roofline     : the dominant kernel by summed time (an MFMA conv instantiation, named as rocprofv3 names it):
+                 algorithmic FLOPs per launch (from the plan: 2 * M * K * Cout) / average launch duration, measured
+                 with HIP events on the launch stream in an eager pass right after the timed region (kernels inside
+                 a replayed hipGraph cannot be bracketed); peak = 157.3 TFLOP/s fp32 MFMA (MI355X_MICROARCH.md);
+                 `traffic` = HBM bytes per launch from the separate rocprofv3 --pmc passes of THE SAME instantiation
+                 and shape (profiles/pmc_dominant_kernel.json, written by tools/profile_round.sh), else null.
+  predict_fps  : (mpii, N=1) what a caller of Model.predict gets -- host numpy arrays in, host arrays out, wall clock
+                 over 512 frames after one warm-up call (method of exp/pennaction/eval_speed2d.py:70-77), for float32
+                 frames and for raw uint8 frames (normalised inside the first convolution).  Never `value`.
+  cpu_baseline : the CPU oracle (a port; TensorFlow/Keras are not installable here) on the host cores of this box:
+                 batch 16, median of 5 after one warm-up.  N=1, rank 0 only.
 """
 import argparse
 import json
@@ -32,9 +45,12 @@ if ROOT not in sys.path:
 
 PEAK_FP32_MFMA_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md "Peak FP32 (matrix)"
 PEAK_HBM_GBS = 8000.0
+TILES = [(2, 2, 2, 3), (2, 2, 2, 2), (4, 1, 1, 3), (4, 1, 1, 2), (4, 1, 1, 1), (2, 1, 1, 3), (2, 1, 1, 2),
+         (2, 1, 1, 1), (1, 1, 1, 1)]
 
 
-def build_model(blocks):
+# ---- models ------------------------------------------------------------------------------------------------------
+def build_mpii(blocks=8):
     from deephar_amd import graph, weights
     from deephar_amd.models import reception
     graph.reset_naming()
@@ -44,8 +60,58 @@ def build_model(blocks):
     return m
 
 
-def cpu_baseline(model, blocks, budget_s=12.0):
-    """Oracle (torch-CPU fp32) frames/s on all host cores; bounded to ~budget_s of CPU work."""
+def build_penn_merge():
+    """exp/pennaction/eval_penn_ar_pe_merge.py:42-57: 16-frame clips, 4 blocks, J=16, 15 actions."""
+    from deephar_amd import graph, weights
+    from deephar_amd.models import reception, action
+    graph.reset_naming()
+    pe = reception.build((256, 256, 3), 16, dim=2, num_blocks=4, num_context_per_joint=2, ksize=(5, 5))
+    m = action.build_merge_model(pe, 15, (256, 256, 3), 16, 16, 4, pose_dim=2, pose_net_version='v1',
+                                 output_poses=True)
+    weights.init_synthetic(m, seed=0)
+    return m
+
+
+def build_ntu_spnet():
+    """exp/ntu/eval_ntu_multitask.py:34-38 with the 32-frame clips BASELINE.json asks for."""
+    from deephar_amd import graph, weights, utils
+    from deephar_amd.config import ModelConfig
+    from deephar_amd.models import spnet
+    graph.reset_naming()
+    cfg = ModelConfig((32, 256, 256, 3), utils.pa17j3d, num_actions=[60], num_pyramids=2, action_pyramids=[1, 2],
+                      num_levels=4, pose_replica=False, num_pose_features=192, num_visual_features=192)
+    m = spnet.build(cfg)
+    weights.init_synthetic(m, seed=0)
+    return m
+
+
+WORKLOADS = {
+    'mpii': dict(build=build_mpii, clips=False, per_gpu=64, T=1,
+                 name='MPII single-person 256x256, ReceptionNet 8 blocks J=16 ctx=2 k=5, pose-only forward, batch=64 '
+                      'per GPU (BASELINE.json configs[1])'),
+    'penn_merge': dict(build=build_penn_merge, clips=True, per_gpu=4, T=16,
+                       name='PennAction pose+action merge model, 16-frame 256x256 clips, 4 blocks, 4 clips per GPU, '
+                            'frame-shard + RCCL all-gather (BASELINE.json configs[3])'),
+    'ntu_spnet': dict(build=build_ntu_spnet, clips=True, per_gpu=8, T=32,
+                      name='NTU multitask SPNet, 32-frame 256x256 clips, 8 clips per GPU, frame-shard + RCCL all-gather '
+                           '(BASELINE.json configs[4])'),
+}
+
+
+# ---- CPU baseline --------------------------------------------------------------------------------------------------
+def cpu_model_string():
+    try:
+        with open('/proc/cpuinfo') as f:
+            for line in f:
+                if line.startswith('model name'):
+                    return line.split(':', 1)[1].strip()
+    except OSError:
+        pass
+    return 'unknown'
+
+
+def cpu_baseline(model, blocks):
+    """Oracle (torch-CPU fp32) frames/s: batch 16, median of 5 after one warm-up."""
     import torch
     from deephar_amd import weights
     from oracle import reception as oref
@@ -55,23 +121,134 @@ def cpu_baseline(model, blocks, budget_s=12.0):
     cores = min(os.cpu_count() or 1, 32)
     torch.set_num_threads(cores)
     wd = Weights(weights.as_dict(model))
-    bs = 4
+    bs = 16
     x = np.random.default_rng(0).uniform(-1, 1, (bs, 256, 256, 3)).astype(np.float32)
     kw = dict(num_context_per_joint=2, num_blocks=blocks, ksize=(5, 5), concat_pose_confidence=False)
     oref.forward(wd, x, 16, 2, **kw)  # warm-up
-    t0 = time.perf_counter()
-    frames = 0
-    while True:
+    ts = []
+    t_all = time.perf_counter()
+    for _ in range(5):
+        t0 = time.perf_counter()
         oref.forward(wd, x, 16, 2, **kw)
-        frames += bs
+        ts.append(time.perf_counter() - t0)
+        if time.perf_counter() - t_all > 25.0:      # bounded sample on a slow host
+            break
+    med = float(np.median(ts))
+    return dict(value=round(bs / med, 2), unit='frames/s', cores=cores, kind='port', cpu=cpu_model_string(),
+                host_logical_cpus=os.cpu_count(),
+                sample='CPU-oracle baseline (stand-in for the reference TF-CPU path; TF/Keras absent from the image): '
+                       'batch of %d frames of the same 256x256x3 workload through oracle/reception.py (PyTorch-CPU '
+                       'fp32, %d threads), median of %d runs after 1 warm-up, %.2f s per batch' % (bs, cores, len(ts), med))
+
+
+# ---- kernel naming / roofline -----------------------------------------------------------------------------------------
+def kernel_name(s):
+    """The template instantiation a conv step launches, spelled as rocprofv3 demangles it."""
+    cfg = s.attrs.get('tile_cfg', -1)
+    if s.kind == 'sepconv':
+        return 'sepconv_fused_kernel (tiling %d)' % cfg
+    if cfg < 0:
+        return 'conv (library-picked tiling)'
+    t = TILES[cfg % 9]
+    b = lambda v: 'true' if v else 'false'
+    a = s.attrs
+    if cfg >= 9:
+        kxk = not (a['kh'] == a['kw'] == 1 and a['sh'] == a['sw'] == 1 and a['pt'] == a['pl'] == 0)
+        return 'gemm1x1_kernel<%d, %d, %d, %d, %s, %s, %s>' % (t + (b(a['up2']), b(a['pre_relu']), b(kxk)))
+    vec4 = s.ins['x'].C % 4 == 0 and s.ins['x'].ld % 4 == 0
+    return 'conv_igemm_kernel<%d, %d, %d, %d, %s, %s>' % (t + (b(vec4), b(a['up2'])))
+
+
+def profile_plans(bound):
+    """bound: [(BoundPlan, stream_ptr)].  Per-step HIP-event times of an eager pass -> (rows, kinds)."""
+    rows, kinds = [], {}
+    for bp, sp in bound:
+        times = bp.profile(sp, reps=3)
+        steps = [c[2] for c in bp.calls]             # includes the stand-alone uint8 normalisation launches, in order
+        for s, ms in zip(steps, times):
+            n = bp.n
+            rows.append((s, float(ms), n))
+            k = kinds.setdefault(s.kind, dict(ms=0.0, flops=0.0, bytes=0.0, launches=0))
+            k['ms'] += float(ms)
+            k['flops'] += s.flops(n)
+            k['bytes'] += s.bytes(n)
+            k['launches'] += 1
+    return rows, kinds
+
+
+def roofline(rows, kinds, total_flops_per_step, ms_per_step):
+    conv_kinds = [k for k in ('conv', 'sepconv') if k in kinds]
+    conv = dict(ms=sum(kinds[k]['ms'] for k in conv_kinds), flops=sum(kinds[k]['flops'] for k in conv_kinds),
+                launches=sum(kinds[k]['launches'] for k in conv_kinds))
+    eager_total_ms = sum(ms for _, ms, _ in rows)
+    by_kernel = {}
+    for s, ms, n in rows:
+        if s.kind not in ('conv', 'sepconv'):
+            continue
+        g = by_kernel.setdefault(kernel_name(s), dict(ms=0.0, flops=0.0, launches=0, shapes={}))
+        g['ms'] += ms
+        g['flops'] += s.flops(n)
+        g['launches'] += 1
+        x, y = s.ins['x'], s.outs['y']
+        key = (n * x.lead(3) * y.shape[-3] * y.shape[-2] // (4 if s.attrs['up2'] else 1), s.attrs['K'], s.attrs['Cout'])
+        sh = g['shapes'].setdefault(key, dict(ms=0.0, launches=0, flops=s.flops(n), bytes=s.bytes(n)))
+        sh['ms'] += ms
+        sh['launches'] += 1
+    dom_name, dom = max(by_kernel.items(), key=lambda kv: kv[1]['ms'])
+    achieved = dom['flops'] / (dom['ms'] * 1e-3) / 1e12
+    # the shape this instantiation spends most of its time on: its algorithmic bytes (operands read once, result
+    # written once: Step.bytes) and, when the PMC passes of the same instantiation + shape exist, its HBM traffic
+    (m_, k_, n_), main = max(dom['shapes'].items(), key=lambda kv: kv[1]['ms'])
+    traffic, traffic_src = None, None
+    pmc_path = os.path.join(ROOT, 'profiles', 'pmc_dominant_kernel.json')
+    if os.path.exists(pmc_path):
+        with open(pmc_path) as f:
+            pmc = json.load(f)
+        ent = pmc.get('kernels', {}).get(dom_name)
+        if ent and [m_, k_, n_] == ent.get('shape_mkn'):
+            traffic = ent['fetch_bytes_per_launch'] + ent['write_bytes_per_launch']
+            traffic_src = ent['source']
+    out = {'bound': 'mfma', 'kernel': dom_name,
+           'achieved': round(achieved, 2), 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
+           'frac': round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), 'traffic': traffic,
+           'traffic_unit': 'bytes/launch (HBM read + write, PMC) of the main shape', 'traffic_source': traffic_src,
+           'main_shape_mkn': [m_, k_, n_], 'main_shape_launches_per_step': main['launches'],
+           'main_shape_avg_launch_us': round(1e3 * main['ms'] / main['launches'], 2),
+           'algorithmic_bytes_per_launch': main['bytes'], 'algorithmic_gflop_per_launch': round(main['flops'] / 1e9, 3),
+           'launches_per_step': dom['launches'],
+           'avg_launch_us': round(1e3 * dom['ms'] / dom['launches'], 2),
+           'gflop_per_launch': round(dom['flops'] / dom['launches'] / 1e9, 2),
+           'share_of_step_time': round(dom['ms'] / eager_total_ms, 4),
+           'all_mfma_conv_kernels': {'launches_per_step': conv['launches'],
+                                     'achieved': round(conv['flops'] / (conv['ms'] * 1e-3) / 1e12, 2),
+                                     'frac': round(conv['flops'] / (conv['ms'] * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4),
+                                     'gflop_per_step': round(conv['flops'] / 1e9, 2)},
+           'whole_forward_frac': round(total_flops_per_step / (ms_per_step * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4)}
+    extra = {'kernel_time_share': {k: round(v['ms'] / eager_total_ms, 4) for k, v in sorted(kinds.items())},
+             'hbm_bound_kernels': {k: {'GBps': round(v['bytes'] / (v['ms'] * 1e-3) / 1e9, 1),
+                                       'frac_of_8TBps': round(v['bytes'] / (v['ms'] * 1e-3) / 1e9 / PEAK_HBM_GBS, 4)}
+                                   for k, v in sorted(kinds.items()) if k in ('dwconv', 'pool', 'sam') and v['ms'] > 0}}
+    return out, extra
+
+
+# ---- Model.predict boundary ------------------------------------------------------------------------------------------
+def predict_boundary(model, batch, frames=512):
+    """Wall-clock frames/s of Model.predict on HOST arrays (H2D of the inputs, hipGraph replays, D2H of every output),
+    one warm-up call first -- the reference's own timing method (exp/pennaction/eval_speed2d.py:70-77)."""
+    rng = np.random.default_rng(7)
+    res = {}
+    for tag in ('f32', 'u8'):
+        if tag == 'f32':
+            x = rng.uniform(-1, 1, (frames, 256, 256, 3)).astype(np.float32)
+        else:
+            x = rng.integers(0, 256, (frames, 256, 256, 3), dtype=np.uint8)
+        model.predict(x[:2 * batch], batch_size=batch)            # warm-up (binds / tunes / captures the plan)
+        t0 = time.perf_counter()
+        out = model.predict(x, batch_size=batch)
         dt = time.perf_counter() - t0
-        if dt >= budget_s or frames >= 256:
-            break
-        if frames == bs and dt > budget_s / 2:   # very slow host: one batch is the sample
-            break
-    return dict(value=round(frames / dt, 2), unit='frames/s', cores=cores, kind='port',
-                sample='%d frames (batches of %d) of the same 256x256x3 workload through oracle/reception.py '
-                       '(PyTorch-CPU fp32, %d threads), %.1f s' % (frames, bs, cores, dt))
+        assert len(out[0]) == frames
+        res[tag] = round(frames / dt, 1)
+    return res
 
 
 def main():
@@ -79,16 +256,18 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=3)
-    ap.add_argument('--batch', type=int, default=64, help='frames per GPU per step (BASELINE cfg 2: 64)')
-    ap.add_argument('--blocks', type=int, default=8)
+    ap.add_argument('--workload', choices=sorted(WORKLOADS), default='mpii')
+    ap.add_argument('--batch', type=int, default=None, help='frames (mpii) or clips (clip workloads) per GPU per step')
+    ap.add_argument('--blocks', type=int, default=8, help='mpii only')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-predict', action='store_true', help='skip the Model.predict boundary measurement')
     ap.add_argument('--no-graph', action='store_true', help='launch kernels eagerly instead of hipGraph replay')
     ap.add_argument('--dump-steps', default=None, help='write the per-kernel profile (JSON) to this path')
     ap.add_argument('--streams', type=int, default=None,
                     help='HIP streams for independent model branches (default: the engine default)')
     ap.add_argument('--input', choices=('f32', 'u8'), default='f32',
-                    help="f32: normalised float frames resident in HBM (what the reference's predict() is handed); "
-                         "u8: raw uint8 frames resident in HBM, normalised inside the first convolution")
+                    help="mpii: f32 = normalised float frames resident in HBM (what the reference's predict() is "
+                         "handed); u8 = raw uint8 frames resident in HBM, normalised inside the first convolution")
     ap.add_argument('--tune-cache', default=None,
                     help='JSON file with the autotuned conv tilings: loaded if present (no tuning launches, '
                          'keeps rocprofv3 kernel stats clean), written otherwise')
@@ -100,181 +279,183 @@ def main():
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit('--gpus %d needs torch.distributed.run with --nproc-per-node %d' % (args.gpus, args.gpus))
+    if world != args.gpus and world == 1 and args.gpus > 1:
+        raise SystemExit('--gpus %d needs torch.distributed.run with --nproc-per-node %d' % (args.gpus, args.gpus))
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs a HIP device (the product path has no CPU fallback)')
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', rank=rank, world_size=world,
-                                device_id=torch.device('cuda', local_rank))
+        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local_rank))
 
     def barrier():
         if world > 1:
             dist.barrier()
 
-    model = build_model(args.blocks)
+    wl = WORKLOADS[args.workload]
+    per_gpu = args.batch or wl['per_gpu']
+    model = wl['build'](args.blocks) if args.workload == 'mpii' else wl['build']()
     if args.streams is not None:
         model.num_streams = args.streams
-    plan = model.plan
-    ex = model.executor
-    ex.use_graph = not args.no_graph
-    n = args.batch
-    if args.tune_cache and os.path.exists(args.tune_cache):
-        with open(args.tune_cache) as f:
-            ex.tune_table = {tuple(json.loads(k)): v for k, v in json.load(f).items()}
-    u8 = args.input == 'u8'
-    bp = ex.bind(n, u8_norm=1 if u8 else None)
-    if args.tune_cache and rank == 0 and not os.path.exists(args.tune_cache):
-        with open(args.tune_cache, 'w') as f:
-            json.dump({json.dumps(list(k)): v for k, v in ex.tune_table.items()}, f)
-    if u8:
-        x = np.random.default_rng(1234 + rank).integers(0, 256, (n, 256, 256, 3), dtype=np.uint8)
-    else:
-        x = np.random.default_rng(1234 + rank).uniform(-1, 1, (n, 256, 256, 3)).astype(np.float32)
-    with torch.cuda.stream(ex.stream):
-        ex.set_inputs(bp, [x])           # inputs resident in HBM before the timed region
-    ex.stream.synchronize()
 
-    def step():
-        # the input buffer is re-used by later activations inside one forward, so every step re-stages the
-        # frames from a second HBM-resident copy (device-to-device, inside the timed region)
+    def load_tune(ex):
+        if args.tune_cache and os.path.exists(args.tune_cache):
+            with open(args.tune_cache) as f:
+                ex.tune_table.update({tuple(tuple(v) if isinstance(v, list) else v for v in json.loads(k)): c
+                                      for k, c in json.load(f).items()})
+
+    def save_tune(tables):
+        if args.tune_cache and rank == 0 and not os.path.exists(args.tune_cache):
+            merged = {}
+            for t in tables:
+                merged.update(t)
+            with open(args.tune_cache, 'w') as f:
+                json.dump({json.dumps(list(k)): v for k, v in merged.items()}, f)
+
+    collective_us = None
+    if not wl['clips']:
+        # ---- frames: replicas, no collective ---------------------------------------------------------------------
+        plan, ex, n = model.plan, model.executor, per_gpu
+        ex.use_graph = not args.no_graph
+        load_tune(ex)
+        u8 = args.input == 'u8'
+        bp = ex.bind(n, u8_norm=1 if u8 else None)
+        save_tune([ex.tune_table])
+        if u8:
+            x = np.random.default_rng(1234 + rank).integers(0, 256, (n, 256, 256, 3), dtype=np.uint8)
+        else:
+            x = np.random.default_rng(1234 + rank).uniform(-1, 1, (n, 256, 256, 3)).astype(np.float32)
         with torch.cuda.stream(ex.stream):
-            if not u8:        # (the uint8 staging buffer lives outside the arena and is never overwritten)
-                bp.tensor(plan.inputs[0]).copy_(x_dev, non_blocking=True)
-            ex.forward(bp)
+            ex.set_inputs(bp, [x])           # inputs resident in HBM before the timed region
+            x_dev = torch.from_numpy(x).to(ex.device)
+        ex.stream.synchronize()
 
-    with torch.cuda.stream(ex.stream):
-        x_dev = torch.from_numpy(x).to(ex.device)
-    ex.stream.synchronize()
+        def step():
+            # the input buffer is re-used by later activations inside one forward, so every step re-stages the
+            # frames from a second HBM-resident copy (device-to-device, inside the timed region)
+            with torch.cuda.stream(ex.stream):
+                if not u8:        # (the uint8 staging buffer lives outside the arena and is never overwritten)
+                    bp.tensor(plan.inputs[0]).copy_(x_dev, non_blocking=True)
+                ex.forward(bp)
+
+        def restage():
+            with torch.cuda.stream(ex.stream):
+                if not u8:
+                    bp.tensor(plan.inputs[0]).copy_(x_dev)
+
+        bound = [(bp, ex.stream_ptr)]
+        streams = [ex.stream]
+        frames_per_step = world * n
+        flops_per_step = plan.total_flops(n)
+        check = lambda: bp.tensor(plan.outputs[-2]).cpu().numpy()
+        parallelism = 'frame-shard x%d (replicas, no collective)' % world
+    else:
+        # ---- clips: frame stage on T/world frames of every clip -> ONE all-gather -> replicated head ----------------
+        from deephar_amd import parallel
+        T = wl['T']
+        clips = per_gpu * world
+        scm = parallel.ShardedClipModel(model, rank=rank, world=world)
+        fm, hm, info = scm.frame_model, scm.head_model, scm.info
+        for mm in (fm, hm):
+            mm.executor.use_graph = not args.no_graph
+            load_tune(mm.executor)
+        x = np.random.default_rng(1234 + rank).uniform(-1, 1, (clips, info['Tl'], 256, 256, 3)).astype(np.float32)
+        x_dev = torch.from_numpy(x).to(fm.executor.device)          # this rank's frames, resident in HBM
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(2 * (args.steps + args.warmup + 4))]
+        pairs = []
+
+        def step():
+            i = len(pairs)
+            pairs.append((ev[2 * i], ev[2 * i + 1]))
+            scm.forward_device(x_dev, events=pairs[-1])
+
+        step()                                                      # binds / tunes both stages
+        pairs.clear()
+        save_tune([fm.executor.tune_table, hm.executor.tune_table])
+        restage = lambda: None
+        fbp = fm.executor.bound[clips]
+        hbp = hm.executor.bound[clips]
+        bound = [(fbp, fm.executor.stream_ptr), (hbp, hm.executor.stream_ptr)]
+        streams = [fm.executor.stream, hm.executor.stream]
+        frames_per_step = clips * T
+        flops_per_step = fm.plan.total_flops(clips) + hm.plan.total_flops(clips)
+        check = lambda: scm.last_outputs[0].cpu().numpy()
+        parallelism = 'frame-shard x%d: T/%d frames of %d clips per rank, one packed all-gather [%d, %d, J, %d] fp32, ' \
+                      'head replicated' % (world, world, clips, clips, info['Tl'], info['packed_channels'])
+
+    def sync_all():
+        for s_ in streams:
+            s_.synchronize()
+        torch.cuda.synchronize()
 
     for _ in range(args.warmup):
         step()
-    ex.stream.synchronize()
-    torch.cuda.synchronize()
+    sync_all()
+    if wl['clips']:
+        pairs.clear()
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
-    ex.stream.synchronize()
-    torch.cuda.synchronize()
+    sync_all()
     barrier()
     dt = time.perf_counter() - t0
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device='cuda')
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+    if wl['clips']:
+        collective_us = round(1e3 * float(np.mean([a.elapsed_time(b) for a, b in pairs])), 2)
 
     # sanity: outputs finite and in range
-    pose = bp.tensor(plan.outputs[-2]).cpu().numpy()
-    ok = bool(np.all(np.isfinite(pose)) and pose.min() >= 0 and pose.max() <= 1)
+    pose = check()
+    ok = bool(np.all(np.isfinite(pose)) and pose[..., :2].min() >= 0 and pose[..., :2].max() <= 1)
 
     # ---- per-kernel pass (HIP events on the launch stream) ----------------------------------------------
-    with torch.cuda.stream(ex.stream):
-        if not u8:
-            bp.tensor(plan.inputs[0]).copy_(x_dev)
-        times_ms = bp.profile(ex.stream_ptr, reps=3)
-    kinds = {}
-    for s, ms in zip(plan.steps, times_ms):
-        k = kinds.setdefault(s.kind, dict(ms=0.0, flops=0.0, bytes=0.0, launches=0))
-        k['ms'] += float(ms)
-        k['flops'] += s.flops(n)
-        k['bytes'] += s.bytes(n)
-        k['launches'] += 1
-    conv = kinds['conv']
-    achieved_all = conv['flops'] / (conv['ms'] * 1e-3) / 1e12
-    eager_total_ms = float(np.sum(times_ms))
-
-    # the dominant KERNEL = the template instantiation (as rocprofv3 names it) with the largest summed time
-    TILES = [(2, 2, 2, 3), (2, 2, 2, 2), (4, 1, 1, 3), (4, 1, 1, 2), (4, 1, 1, 1), (2, 1, 1, 3), (2, 1, 1, 2),
-             (2, 1, 1, 1), (1, 1, 1, 1)]
-
-    def kernel_name(s):
-        cfg = s.attrs.get('tile_cfg', -1)
-        if cfg < 0:
-            return 'conv (library-picked tiling)'
-        t = TILES[cfg % 9]
-        b = lambda v: 'true' if v else 'false'
-        if cfg >= 9:
-            a = s.attrs
-            kxk = not (a['kh'] == a['kw'] == 1 and a['sh'] == a['sw'] == 1 and a['pt'] == a['pl'] == 0)
-            return 'gemm1x1_kernel<%d, %d, %d, %d, %s, %s, %s>' % (t + (b(a['up2']), b(a['pre_relu']), b(kxk)))
-        vec4 = s.ins['x'].C % 4 == 0 and s.ins['x'].ld % 4 == 0
-        return 'conv_igemm_kernel<%d, %d, %d, %d, %s, %s>' % (t + (b(vec4), b(s.attrs['up2'])))
-
-    by_kernel = {}
-    for s, ms in zip(plan.steps, times_ms):
-        if s.kind != 'conv':
-            continue
-        g = by_kernel.setdefault(kernel_name(s), dict(ms=0.0, flops=0.0, launches=0))
-        g['ms'] += float(ms)
-        g['flops'] += s.flops(n)
-        g['launches'] += 1
-    dom_name, dom = max(by_kernel.items(), key=lambda kv: kv[1]['ms'])
-    achieved = dom['flops'] / (dom['ms'] * 1e-3) / 1e12
-
-    # HBM traffic of the dominant kernel: PMC counters cannot be read from inside this process; the per-launch
-    # figure comes from the separate rocprofv3 --pmc passes recorded under profiles/ (same kernel, same shape)
-    traffic, traffic_src = None, None
-    pmc_path = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'pmc_dominant_kernel.json')
-    main_shape_launches = sum(1 for s_ in plan.steps if s_.kind == 'conv' and kernel_name(s_) == dom_name and
-                              abs(s_.flops(n) / 1e9 - 43.49) < 0.01)
-    if os.path.exists(pmc_path) and dom_name.startswith('gemm1x1_kernel') and n == 64 and main_shape_launches:
-        with open(pmc_path) as f:
-            pmc = json.load(f)
-        traffic = pmc['fetch_bytes_per_launch'] + pmc['write_bytes_per_launch']
-        traffic_src = '%s (applies to the %d of %d launches of this kernel that are the 65536 x 576 x 576 GEMM)' % (
-            pmc['source'], main_shape_launches, dom['launches'])
+    restage()
+    rows, kinds = profile_plans(bound)
+    ms_per_step = 1e3 * dt / args.steps
+    roof, extra = roofline(rows, kinds, flops_per_step, ms_per_step)
 
     if rank == 0:
-        value = world * n * args.steps / dt
         out = {
-            'metric': 'frames/sec whole-node, 256x256 MPII pose fwd',
-            'value': round(value, 1),
+            'metric': 'frames/sec whole-node, 256x256 MPII pose fwd' if args.workload == 'mpii' else
+                      'frames/sec whole-node, 256x256 pose + action fwd (%s)' % args.workload,
+            'value': round(frames_per_step * args.steps / dt, 1),
             'unit': 'frames/s',
             'n_gpus': world,
             'steps': args.steps,
             'warmup': args.warmup,
-            'ms_per_step': round(1e3 * dt / args.steps, 3),
+            'ms_per_step': round(ms_per_step, 3),
             'higher_is_better': True,
             'scaling': 'weak',
             'vs_baseline': None,
             'dtype': 'f32',
             'data': 'synthetic',
-            'config': {'workload': 'MPII single-person 256x256, ReceptionNet %d blocks J=16 ctx=2 k=5, pose-only '
-                                   'forward, batch=%d per GPU (BASELINE.json configs[1])' % (args.blocks, n),
-                       'global_batch': world * n, 'parallelism': 'frame-shard x%d (no collective)' % world,
-                       'hipgraph': not args.no_graph, 'streams': plan.nstreams, 'input': args.input, 'outputs_finite_in_range': ok},
-            'roofline': {'bound': 'mfma', 'kernel': dom_name,
-                         'achieved': round(achieved, 2), 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
-                         'frac': round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), 'traffic': traffic,
-                         'traffic_unit': 'bytes/launch (HBM read + write, PMC)', 'traffic_source': traffic_src,
-                         'algorithmic_bytes_per_launch': 454e6 if traffic else None,
-                         'launches_per_step': dom['launches'],
-                         'avg_launch_us': round(1e3 * dom['ms'] / dom['launches'], 2),
-                         'gflop_per_launch': round(dom['flops'] / dom['launches'] / 1e9, 2),
-                         'share_of_step_time': round(dom['ms'] / eager_total_ms, 4),
-                         'all_mfma_conv_kernels': {'launches_per_step': conv['launches'],
-                                                   'achieved': round(achieved_all, 2),
-                                                   'frac': round(achieved_all / PEAK_FP32_MFMA_TFLOPS, 4),
-                                                   'gflop_per_step': round(conv['flops'] / 1e9, 2)},
-                         'whole_forward_frac': round(plan.total_flops(n) * args.steps / dt / 1e12 /
-                                                     PEAK_FP32_MFMA_TFLOPS, 4)},
-            'kernel_time_share': {k: round(v['ms'] / eager_total_ms, 4) for k, v in sorted(kinds.items())},
-            'hbm_bound_kernels': {k: {'GBps': round(v['bytes'] / (v['ms'] * 1e-3) / 1e9, 1),
-                                      'frac_of_8TBps': round(v['bytes'] / (v['ms'] * 1e-3) / 1e9 / PEAK_HBM_GBS, 4)}
-                                  for k, v in sorted(kinds.items()) if k in ('dwconv', 'pool', 'sam') and v['ms'] > 0},
+            'config': {'workload': wl['name'] if args.workload != 'mpii' or (args.blocks == 8 and per_gpu == 64) else
+                       'MPII single-person 256x256, ReceptionNet %d blocks, batch=%d per GPU' % (args.blocks, per_gpu),
+                       'global_batch': per_gpu * world, 'frames_per_step': frames_per_step, 'parallelism': parallelism,
+                       'hipgraph': not args.no_graph, 'streams': model.plan.nstreams, 'input': args.input,
+                       'outputs_finite_in_range': ok},
+            'roofline': roof,
         }
-        if world == 1 and not args.no_cpu_baseline:
+        out.update(extra)
+        if collective_us is not None:
+            out['collective_us'] = collective_us
+            out['rccl_ranks'] = world
+        if args.workload == 'mpii' and world == 1 and not args.no_predict:
+            fps = predict_boundary(model, per_gpu)
+            out['predict_fps_f32'], out['predict_fps_u8'] = fps['f32'], fps['u8']
+            out['predict_note'] = 'Model.predict on host numpy arrays, 512 frames in batches of %d, wall clock incl. ' \
+                                  'H2D of the frames and D2H of all outputs, after one warm-up call' % per_gpu
+        if world == 1 and not args.no_cpu_baseline and args.workload == 'mpii':
             out['cpu_baseline'] = cpu_baseline(model, args.blocks)
         if args.dump_steps:
-            rows = [dict(kind=s.kind, name=s.name, ms=float(ms), gflop=s.flops(n) / 1e9, mbytes=s.bytes(n) / 1e6,
-                         out=list(next(iter(s.outs.values())).shape) if s.outs else None)
-                    for s, ms in zip(plan.steps, times_ms)]
+            dump = [dict(kind=s.kind, name=s.name, kernel=kernel_name(s) if s.kind in ('conv', 'sepconv') else s.kind,
+                         ms=ms, gflop=s.flops(n) / 1e9, mbytes=s.bytes(n) / 1e6,
+                         out=list(next(iter(s.outs.values())).shape) if s.outs else None) for s, ms, n in rows]
             with open(args.dump_steps, 'w') as f:
-                json.dump(rows, f, indent=1)
+                json.dump(dump, f, indent=1)
         print(json.dumps(out))
     if world > 1:
         dist.barrier()

@@ -640,18 +640,127 @@ class Executor:
             bp.launch_all(self.stream_ptr)
 
     def run(self, arrays, n=None, u8_norm=None):
-        """arrays: list of host arrays with equal leading dim m.  Returns list of np.float32 outputs."""
+        """arrays: list of host arrays with equal leading dim m <= n.  Returns list of np.float32 outputs."""
+        return self.run_pipelined(arrays, n or arrays[0].shape[0], u8_norm=u8_norm)
+
+    # ---- the Model.predict boundary: host arrays in, host arrays out ---------------------------------------------
+    def _io(self, bp):
+        """Per bound plan: two slots of pinned host staging (inputs in the dtype that crosses PCIe: uint8 frames or
+        float32 -- float64 loader arrays are cast on the HOST while being copied into the pinned buffer), their
+        device twins, one pinned buffer for the packed outputs, and the events that order the three engines."""
+        io = getattr(bp, '_io', None)
+        if io is None:
+            torch = _torch()
+            dt = torch.uint8 if bp.u8 is not None else torch.float32
+            io = dict(host_in=[], dev_in=[], host_out=[], h2d=[], done=[], pending=[None, None])
+            for _ in range(2):
+                io['host_in'].append([torch.empty((bp.n,) + v.shape, dtype=dt, pin_memory=True) for v in self.plan.inputs])
+                io['dev_in'].append([torch.empty((bp.n,) + v.shape, dtype=dt, device=self.device) for v in self.plan.inputs])
+                io['host_out'].append(torch.empty(max(self.plan.out_items * bp.n, 1), dtype=torch.float32, pin_memory=True))
+                io['h2d'].append(torch.cuda.Event())
+                io['done'].append(torch.cuda.Event())
+            bp._io = io
+        return io
+
+    def _host_outputs(self, bp, flat, m):
+        """Slice the packed output region (host copy of arena[0 : out_items * n]) into one fresh array per output."""
         torch = _torch()
-        m = arrays[0].shape[0]
+        outs = []
+        for v in self.plan.outputs:
+            shape = (bp.n,) + v.shape
+            strides = [1] * len(shape)
+            if len(shape) >= 2:
+                strides[-2] = v.ld
+                for i in range(len(shape) - 3, -1, -1):
+                    strides[i] = strides[i + 1] * shape[i + 1]
+            view = torch.as_strided(flat, shape, strides, v.buf.offset * bp.n + v.coff)
+            outs.append(np.array(view[:m].numpy(), dtype=np.float32, copy=True, order='C'))
+        return outs
+
+    def run_pipelined(self, arrays, bs, u8_norm=None, verbose=0):
+        """Forward over all rows of `arrays` (host arrays, equal leading dim) in chunks of `bs`, as a 3-stage pipeline:
+             host   : cast / copy chunk i+1 into pinned staging      (overlaps the GPU working on chunk i)
+             copy   : pinned -> device staging on a copy stream      (overlaps the graph replay of chunk i)
+             compute: staging -> plan input (D2D), hipGraph replay, ONE packed D2H of all outputs into pinned memory
+           Returns one np.float32 array per model output, rows in input order (keras Model.predict semantics:
+           exp/common/*_tools.py; timing method of exp/pennaction/eval_speed2d.py:70-77)."""
+        torch = _torch()
+        total = arrays[0].shape[0]
+        bs = int(min(bs, total))
+        with torch.cuda.device(self.device):
+            if self.bound:
+                self.sync_weights()
+            with torch.cuda.stream(self.stream):
+                bp = self.bind(bs, u8_norm=u8_norm)
+            if self._wstamp is None:
+                self._wstamp = self._weight_stamp()
+            if getattr(self, 'copy_stream', None) is None:
+                self.copy_stream = torch.cuda.Stream(device=self.device)
+            io = self._io(bp)
+            want = torch.uint8 if bp.u8 is not None else torch.float32
+            results = []
+
+            def collect(slot):
+                m = io['pending'][slot]
+                if m is not None:
+                    io['done'][slot].synchronize()
+                    results.append(self._host_outputs(bp, io['host_out'][slot], m))
+                    io['pending'][slot] = None
+
+            for ci, start in enumerate(range(0, total, bs)):
+                slot = ci & 1
+                collect(slot)                               # chunk ci-2 used this slot: its outputs are on the host now
+                m = min(bs, total - start)
+                for k, (v, arr) in enumerate(zip(self.plan.inputs, arrays)):
+                    part = arr[start:start + m]
+                    if tuple(part.shape[1:]) != tuple(v.shape):
+                        raise ValueError('input has shape %s, model expects [N, %s]' % (tuple(arr.shape), tuple(v.shape)))
+                    src = torch.from_numpy(np.ascontiguousarray(part)) if isinstance(part, np.ndarray) else part
+                    if (src.dtype == torch.uint8) != (want == torch.uint8):
+                        raise ValueError('plan bound for %s inputs, got %s' % (want, src.dtype))
+                    if src.is_cuda:
+                        io['dev_in'][slot][k][:m].copy_(src)                      # caller already holds device data
+                    else:
+                        io['host_in'][slot][k][:m].copy_(src)                     # host-side cast (f64 -> f32) + pin
+                with torch.cuda.stream(self.copy_stream):
+                    for k, arr in enumerate(arrays):
+                        if not (not isinstance(arr, np.ndarray) and arr.is_cuda):
+                            io['dev_in'][slot][k][:m].copy_(io['host_in'][slot][k][:m], non_blocking=True)
+                    io['h2d'][slot].record(self.copy_stream)
+                with torch.cuda.stream(self.stream):
+                    self.stream.wait_event(io['h2d'][slot])
+                    for k, v in enumerate(self.plan.inputs):
+                        dst = bp.u8[id(v.buf)][0] if bp.u8 is not None else bp.tensor(v)
+                        dst[:m].copy_(io['dev_in'][slot][k][:m], non_blocking=True)
+                    self.forward(bp)
+                    io['host_out'][slot].copy_(bp.arena[:io['host_out'][slot].numel()], non_blocking=True)
+                    io['done'][slot].record(self.stream)
+                io['pending'][slot] = m
+                if verbose:
+                    print('%d/%d' % (start + m, total))
+            nchunks = (total + bs - 1) // bs
+            for slot in ((nchunks & 1), ((nchunks + 1) & 1)):       # oldest pending chunk first
+                collect(slot)
+        nout = len(self.plan.outputs)
+        return [np.concatenate([r[k] for r in results], axis=0) if len(results) > 1 else results[0][k]
+                for k in range(nout)]
+
+    def run_device(self, tensors, n=None):
+        """Device tensors in ([m <= n, ...] float32 on this device), device VIEWS of the outputs out (valid until the
+        next forward of the same bound plan); everything is enqueued on `self.stream`, nothing touches the host.
+        Used by the frame-sharded clip runtime (parallel.py) around the RCCL all-gather."""
+        torch = _torch()
+        m = tensors[0].shape[0]
         n = n or m
         with torch.cuda.device(self.device), torch.cuda.stream(self.stream):
             if self.bound:
                 self.sync_weights()
-            bp = self.bind(n, u8_norm=u8_norm)
+            bp = self.bind(n)
             if self._wstamp is None:
                 self._wstamp = self._weight_stamp()
-            self.set_inputs(bp, arrays)
+            for v, t in zip(self.plan.inputs, tensors):
+                if tuple(t.shape[1:]) != tuple(v.shape) or m > bp.n:
+                    raise ValueError('input has shape %s, model expects [<=%d, %s]' % (tuple(t.shape), bp.n, v.shape))
+                bp.tensor(v)[:m].copy_(t, non_blocking=True)
             self.forward(bp)
-            outs = [bp.tensor(v)[:m].contiguous().cpu() for v in self.plan.outputs]
-        self.stream.synchronize()
-        return [o.numpy() for o in outs]
+            return [bp.tensor(v)[:m] for v in self.plan.outputs]

@@ -101,6 +101,7 @@ class Plan:
         self.outputs = []      # Values of the model outputs
         self.bufs = []
         self.arena_items = 0   # floats per batch item
+        self.out_items = 0     # the model outputs occupy [0, out_items) of it (schedule.allocate)
         self.params = []       # ordered unique graph.Param list
         self.nstreams = 1
 

@@ -162,8 +162,18 @@ def allocate(plan, reach):
             return False
         return (my & ~after_x) == 0
 
+    # model outputs first, back to back from offset 0: ONE device-to-host copy of [0, out_items * n) returns them all
     placed = []
+    off = 0
+    for b in plan.bufs:
+        if b.pinned:
+            b.offset = off
+            off += b.items
+            placed.append(b)
+    plan.out_items = off
     for b in sorted(plan.bufs, key=lambda b: -b.items):
+        if b.pinned:
+            continue
         spans = sorted((p.offset, p.offset + p.items) for p in placed if not (ordered(p, b) or ordered(b, p)))
         off = 0
         for lo, hi in spans:

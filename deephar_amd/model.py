@@ -202,16 +202,7 @@ class Model:
             return outs[0] if len(outs) == 1 else outs
         ex = self.executor
         bs = int(min(batch_size or total, total))
-        chunks = []
-        for i in range(0, total, bs):
-            part = [a[i:i + bs] for a in xs]
-            chunks.append(ex.run(part, n=bs, u8_norm=u8_norm))
-            if verbose:
-                print('%d/%d' % (min(i + bs, total), total))
-        if not chunks:
-            outs = [np.zeros((0,) + t.shape, np.float32) for t in self.outputs]
-        else:
-            outs = [np.concatenate([c[k] for c in chunks], axis=0) for k in range(len(self.outputs))]
+        outs = ex.run_pipelined(xs, bs, u8_norm=u8_norm, verbose=verbose)
         return outs[0] if len(outs) == 1 else outs
 
 

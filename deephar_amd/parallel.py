@@ -127,60 +127,97 @@ def split_frames(model, shards):
 # runtime
 # ---------------------------------------------------------------------------------------------------------
 
-def all_gather_frames(local, group=None):
+def all_gather_frames(local, group=None, world=None):
     """All-gather a [N, T_local, ...] tensor along the frame axis -> [N, T, ...].  Works on CUDA tensors
     (RCCL) and CPU tensors (gloo).  One collective per call."""
     import torch
     import torch.distributed as dist
-    world = dist.get_world_size(group)
+    world = dist.get_world_size(group) if world is None else world
     if world == 1:
         return local
     local = local.contiguous()
-    parts = [torch.empty_like(local) for _ in range(world)]
-    dist.all_gather(parts, local, group=group)
-    return torch.cat(parts, dim=1)
+    n = local.shape[0]
+    gathered = torch.empty((world * n,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+    dist.all_gather_into_tensor(gathered, local, group=group)            # rank-major: [G * N, Tl, ...]
+    gathered = gathered.view((world, n) + tuple(local.shape[1:]))
+    return gathered.movedim(0, 1).reshape((n, world * local.shape[1]) + tuple(local.shape[2:]))
 
 
 class ShardedClipModel:
     """Frame-sharded execution of a clip model over the ranks of a process group.
 
+    Default (HIP) path, device resident end to end: this rank's frames [N, T/G, H, W, C] (host array or device tensor)
+    -> frame stage (hipGraph replay, `Executor.run_device`) -> packed device view [N, T/G, J, Cp] -> ONE all-gather
+    (RCCL over xGMI) -> the head stage's inputs are channel slices of the gathered tensor, copied device-to-device into
+    its plan -> head stage (hipGraph replay) -> device views of the outputs; only `predict` copies results to the host.
+
     frame_fn(x_local [N, T/G, H, W, C]) -> packed [N, T/G, J, Cp] (torch tensor, any device)
     head_fn(list of [N, T, J, c_i])     -> list of arrays / tensors
-    The defaults run the two stages on the HIP engine; tests inject CPU stand-ins to exercise the collective
-    and the bookkeeping with the gloo backend."""
+    may be injected: the CPU tests put oracle stand-ins there to exercise the collective and the bookkeeping with the
+    gloo backend."""
 
     def __init__(self, model, rank=None, world=None, group=None, frame_fn=None, head_fn=None):
-        import torch.distributed as dist
+        if rank is None or world is None:
+            import torch.distributed as dist
+            rank = dist.get_rank(group) if rank is None else rank
+            world = dist.get_world_size(group) if world is None else world
         self.group = group
-        self.rank = dist.get_rank(group) if rank is None else rank
-        self.world = dist.get_world_size(group) if world is None else world
+        self.rank, self.world = rank, world
         self.model = model
         self.frame_model, self.head_model, self.info = split_frames(model, self.world)
         self.frame_fn = frame_fn or self._frame_hip
         self.head_fn = head_fn or self._head_hip
+        self.last_outputs = None
 
     # -- default stages on the GPU -----------------------------------------------------------------------
     def _frame_hip(self, x_local):
         import torch
-        out = self.frame_model.predict(x_local, batch_size=len(x_local))
-        return torch.from_numpy(out).to(self.frame_model.executor.device)
+        ex = self.frame_model.executor
+        if isinstance(x_local, np.ndarray):
+            x_local = torch.from_numpy(np.ascontiguousarray(x_local, dtype=np.float32)).to(ex.device)
+        out = ex.run_device([x_local])[0]                       # device view of the packed tensor, on ex.stream
+        torch.cuda.current_stream().wait_stream(ex.stream)      # the collective runs behind torch's current stream
+        return out
 
     def _head_hip(self, tensors):
-        outs = self.head_model.predict([t.cpu().numpy() for t in tensors], batch_size=len(tensors[0]))
-        return outs if isinstance(outs, list) else [outs]
+        import torch
+        ex = self.head_model.executor
+        ex.stream.wait_stream(torch.cuda.current_stream())      # ... and the head stage behind the collective
+        return ex.run_device(tensors)
 
-    def predict(self, clips):
-        """clips: [N, T, H, W, C] (the same array on every rank).  Returns the model's outputs (host arrays)."""
+    def forward_device(self, x_local, events=None):
+        """One clip batch, nothing leaves the device.  `events` = (start, stop) torch events recorded around the
+        collective on the current stream (bench.py: collective_us).  Returns the outputs in model order."""
         info = self.info
-        lo = self.rank * info['Tl']
-        packed = self.frame_fn(np.ascontiguousarray(clips[:, lo:lo + info['Tl']]))
-        full = all_gather_frames(packed, self.group)                       # [N, T, J, Cp]
+        packed = self.frame_fn(x_local)
+        if events is not None:
+            events[0].record()
+        full = all_gather_frames(packed, self.group, self.world)             # [N, T, J, Cp]
+        if events is not None:
+            events[1].record()
         parts = [full[..., off:off + c] for (_, off, c) in info['cut']]
         outs = [None] * len(self.model.outputs)
         for k, ci in info['passthrough'].items():
-            outs[k] = parts[ci].contiguous().cpu().numpy()
+            outs[k] = parts[ci]
         if self.head_model is not None:
-            head = self.head_fn([p.contiguous() for p in parts])
+            head = self.head_fn(parts)
             for k, o in zip(info['head_outputs'], head):
-                outs[k] = o if isinstance(o, np.ndarray) else o.cpu().numpy()
+                outs[k] = o
+        self.last_outputs = outs
         return outs
+
+    def predict(self, clips):
+        """clips: [N, T, H, W, C] (the same array on every rank).  Returns the model's outputs (host arrays)."""
+        import torch
+        info = self.info
+        lo = self.rank * info['Tl']
+        outs = self.forward_device(np.ascontiguousarray(clips[:, lo:lo + info['Tl']]))
+        if self.head_model is not None and self.head_fn == self._head_hip:
+            self.head_model.executor.stream.synchronize()
+        res = []
+        for o in outs:
+            if isinstance(o, np.ndarray):
+                res.append(o)
+            else:
+                res.append(o.contiguous().cpu().numpy() if o.is_cuda else np.ascontiguousarray(o.numpy()))
+        return res

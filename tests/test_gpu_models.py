@@ -469,3 +469,62 @@ def test_fused_sepconv_plan_is_bit_identical(hip_lib, cuda):
     got = f.predict(x, batch_size=3)
     for a, b in zip(ref, got):
         assert np.array_equal(a, b)
+
+
+def test_keras_h5_weight_files_drive_the_gpu_model(hip_lib, cuda, tmp_path):
+    """SURVEY.md 8f rank 1 on the GPU: a Keras-layout .h5 written by save_weights is loaded BY ORDER into a fresh
+    ReceptionNet (eval_mpii_singleperson.py:54) and BY NAME into a fresh SPNet (eval_penn_multitask.py:76) whose weights
+    were different before; predict then reproduces the source model bit for bit and sits within tolerance of the
+    oracle.  The same file re-written by the real libhdf5 (h5py under /opt/conda, every dataset chunked + gzip +
+    shuffle) loads to the same bits."""
+    import subprocess
+    from deephar_amd import weights
+    kw = dict(num_context_per_joint=2)
+    src, wd = _build(2, 1, 16, **kw)
+    x = np.random.default_rng(13).uniform(-1, 1, (2, 256, 256, 3)).astype(np.float32)
+    ref = src.predict(x, batch_size=2)
+    path = str(tmp_path / 'reception.h5')
+    src.save_weights(path)
+    dst, _ = _build(2, 1, 16, **kw)
+    weights.init_synthetic(dst, seed=3)
+    assert not np.array_equal(dst.predict(x, batch_size=2), ref)          # (also binds the plan with OTHER weights)
+    dst.load_weights(path)
+    got = dst.predict(x, batch_size=2)
+    assert np.array_equal(got, ref)
+    o64, _ = _oracle(wd, x, 2, 1, 16, torch.float64, **kw)
+    o32, _ = _oracle(wd, x, 2, 1, 16, torch.float32, **kw)
+    _check('h5.by_order.xy', got[..., :2], o32[0][..., :2], o64[0][..., :2], PX_TOL)
+
+    conda = '/opt/conda/bin/python3.9'
+    if os.path.exists(conda):
+        lib_path = str(tmp_path / 'reception_libhdf5.h5')
+        script = (
+            "import h5py, sys\n"
+            "src, dst = h5py.File(sys.argv[1], 'r'), h5py.File(sys.argv[2], 'w')\n"
+            "for k, v in src.attrs.items(): dst.attrs[k] = v\n"
+            "def walk(g, out):\n"
+            "    for k, v in g.attrs.items(): out.attrs[k] = v\n"
+            "    for name, item in g.items():\n"
+            "        if isinstance(item, h5py.Group): walk(item, out.create_group(name))\n"
+            "        elif item.shape == (): out.create_dataset(name, data=item[()])\n"
+            "        else: out.create_dataset(name, data=item[...], chunks=tuple(max(1, s // 2) for s in item.shape),\n"
+            "                                 compression='gzip', shuffle=True)\n"
+            "walk(src, dst)\n")
+        r = subprocess.run([conda, '-c', script, path, lib_path], capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
+        dst2, _ = _build(2, 1, 16, **kw)
+        weights.init_synthetic(dst2, seed=4)
+        dst2.load_weights(lib_path)
+        assert np.array_equal(dst2.predict(x, batch_size=2), ref)
+
+    # SPNet: every layer is named, files are loaded by name
+    xs = np.random.default_rng(14).uniform(-1, 1, (1, 2, 256, 256, 3)).astype(np.float32)
+    sp, _, _, _ = _spnet(2, 'pa16j2d', 15, 2, [2], 160, replica=True)
+    ref_sp = sp.predict(xs, batch_size=1)
+    sp_path = str(tmp_path / 'spnet.h5')
+    sp.save_weights(sp_path)
+    sp2, _, _, _ = _spnet(2, 'pa16j2d', 15, 2, [2], 160, replica=True)
+    weights.init_synthetic(sp2, seed=5)
+    sp2.load_weights(sp_path, by_name=True)
+    for a, b in zip(sp2.predict(xs, batch_size=1), ref_sp):
+        assert np.array_equal(a, b)

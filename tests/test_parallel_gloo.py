@@ -74,7 +74,7 @@ def test_frame_sharded_clip_model_two_ranks():
     procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
         p.start()
-    res = [q.get(timeout=500) for _ in procs]
+    res = [q.get(timeout=240) for _ in procs]
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
