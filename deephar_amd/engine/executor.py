@@ -644,22 +644,22 @@ class Executor:
         return self.run_pipelined(arrays, n or arrays[0].shape[0], u8_norm=u8_norm)
 
     # ---- the Model.predict boundary: host arrays in, host arrays out ---------------------------------------------
-    def _io(self, bp):
-        """Per bound plan: two slots of pinned host staging (inputs in the dtype that crosses PCIe: uint8 frames or
-        float32 -- float64 loader arrays are cast on the HOST while being copied into the pinned buffer), their
-        device twins, one pinned buffer for the packed outputs, and the events that order the three engines."""
+    def _io(self, bp, depth):
+        """Per bound plan: a ring of `depth` slots of pinned host staging (inputs in the dtype that crosses PCIe: uint8
+        frames or float32 -- float64 loader arrays are cast on the HOST while being copied into the pinned buffer),
+        their device twins, one pinned buffer per slot for the packed outputs, and the events ordering the streams."""
         io = getattr(bp, '_io', None)
         if io is None:
-            torch = _torch()
-            dt = torch.uint8 if bp.u8 is not None else torch.float32
-            io = dict(host_in=[], dev_in=[], host_out=[], h2d=[], done=[], pending=[None, None])
-            for _ in range(2):
-                io['host_in'].append([torch.empty((bp.n,) + v.shape, dtype=dt, pin_memory=True) for v in self.plan.inputs])
-                io['dev_in'].append([torch.empty((bp.n,) + v.shape, dtype=dt, device=self.device) for v in self.plan.inputs])
-                io['host_out'].append(torch.empty(max(self.plan.out_items * bp.n, 1), dtype=torch.float32, pin_memory=True))
-                io['h2d'].append(torch.cuda.Event())
-                io['done'].append(torch.cuda.Event())
-            bp._io = io
+            io = bp._io = dict(host_in=[], dev_in=[], host_out=[], h2d=[], done=[], pending=[])
+        torch = _torch()
+        dt = torch.uint8 if bp.u8 is not None else torch.float32
+        while len(io['host_in']) < depth:
+            io['host_in'].append([torch.empty((bp.n,) + v.shape, dtype=dt, pin_memory=True) for v in self.plan.inputs])
+            io['dev_in'].append([torch.empty((bp.n,) + v.shape, dtype=dt, device=self.device) for v in self.plan.inputs])
+            io['host_out'].append(torch.empty(max(self.plan.out_items * bp.n, 4), dtype=torch.float32, pin_memory=True))
+            io['h2d'].append(torch.cuda.Event())
+            io['done'].append(torch.cuda.Event())
+            io['pending'].append(None)
         return io
 
     def _host_outputs(self, bp, flat, m):
@@ -679,14 +679,21 @@ class Executor:
 
     def run_pipelined(self, arrays, bs, u8_norm=None, verbose=0):
         """Forward over all rows of `arrays` (host arrays, equal leading dim) in chunks of `bs`, as a 3-stage pipeline:
-             host   : cast / copy chunk i+1 into pinned staging      (overlaps the GPU working on chunk i)
+             host   : cast / copy chunk i+k into pinned staging      (overlaps the GPU working on chunk i)
              copy   : pinned -> device staging on a copy stream      (overlaps the graph replay of chunk i)
-             compute: staging -> plan input (D2D), hipGraph replay, ONE packed D2H of all outputs into pinned memory
+             compute: staging -> plan input (D2D), hipGraph replay, ONE D2H of the packed outputs of the whole model
+                      (arena[0 : out_items * n]) into pinned memory.
+           The ring of staging slots is DEEP (up to DEEPHAR_PREDICT_DEPTH = 8 chunks in flight): on this stack every
+           host-side wait that actually has to block (hipEventSynchronize, hipStreamSynchronize, or polling a flag the
+           GPU writes) is followed by a 40-70 ms hole in the GPU's timeline, even though later chunks are already
+           queued (profiles/r02_predict_boundary.md) -- so the host enqueues ahead and waits as late as it can.
            Returns one np.float32 array per model output, rows in input order (keras Model.predict semantics:
            exp/common/*_tools.py; timing method of exp/pennaction/eval_speed2d.py:70-77)."""
         torch = _torch()
         total = arrays[0].shape[0]
         bs = int(min(bs, total))
+        nchunks = (total + bs - 1) // bs
+        depth = max(2, min(nchunks, int(os.environ.get('DEEPHAR_PREDICT_DEPTH', '8'))))
         with torch.cuda.device(self.device):
             if self.bound:
                 self.sync_weights()
@@ -696,7 +703,7 @@ class Executor:
                 self._wstamp = self._weight_stamp()
             if getattr(self, 'copy_stream', None) is None:
                 self.copy_stream = torch.cuda.Stream(device=self.device)
-            io = self._io(bp)
+            io = self._io(bp, depth)
             want = torch.uint8 if bp.u8 is not None else torch.float32
             results = []
 
@@ -708,9 +715,10 @@ class Executor:
                     io['pending'][slot] = None
 
             for ci, start in enumerate(range(0, total, bs)):
-                slot = ci & 1
-                collect(slot)                               # chunk ci-2 used this slot: its outputs are on the host now
+                slot = ci % depth
+                collect(slot)                               # chunk ci-depth used this slot
                 m = min(bs, total - start)
+                on_dev = []
                 for k, (v, arr) in enumerate(zip(self.plan.inputs, arrays)):
                     part = arr[start:start + m]
                     if tuple(part.shape[1:]) != tuple(v.shape):
@@ -718,17 +726,18 @@ class Executor:
                     src = torch.from_numpy(np.ascontiguousarray(part)) if isinstance(part, np.ndarray) else part
                     if (src.dtype == torch.uint8) != (want == torch.uint8):
                         raise ValueError('plan bound for %s inputs, got %s' % (want, src.dtype))
+                    on_dev.append(bool(src.is_cuda))
                     if src.is_cuda:
                         io['dev_in'][slot][k][:m].copy_(src)                      # caller already holds device data
                     else:
                         io['host_in'][slot][k][:m].copy_(src)                     # host-side cast (f64 -> f32) + pin
                 with torch.cuda.stream(self.copy_stream):
-                    for k, arr in enumerate(arrays):
-                        if not (not isinstance(arr, np.ndarray) and arr.is_cuda):
+                    for k in range(len(arrays)):
+                        if not on_dev[k]:
                             io['dev_in'][slot][k][:m].copy_(io['host_in'][slot][k][:m], non_blocking=True)
                     io['h2d'][slot].record(self.copy_stream)
                 with torch.cuda.stream(self.stream):
-                    self.stream.wait_event(io['h2d'][slot])
+                    self.stream.wait_event(io['h2d'][slot])                       # GPU-side wait
                     for k, v in enumerate(self.plan.inputs):
                         dst = bp.u8[id(v.buf)][0] if bp.u8 is not None else bp.tensor(v)
                         dst[:m].copy_(io['dev_in'][slot][k][:m], non_blocking=True)
@@ -738,12 +747,11 @@ class Executor:
                 io['pending'][slot] = m
                 if verbose:
                     print('%d/%d' % (start + m, total))
-            nchunks = (total + bs - 1) // bs
-            for slot in ((nchunks & 1), ((nchunks + 1) & 1)):       # oldest pending chunk first
-                collect(slot)
-        nout = len(self.plan.outputs)
+            for k in range(depth):                                  # oldest pending chunk first
+                collect((nchunks + k) % depth)
+        nres = len(self.plan.outputs)
         return [np.concatenate([r[k] for r in results], axis=0) if len(results) > 1 else results[0][k]
-                for k in range(nout)]
+                for k in range(nres)]
 
     def run_device(self, tensors, n=None):
         """Device tensors in ([m <= n, ...] float32 on this device), device VIEWS of the outputs out (valid until the
