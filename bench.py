@@ -251,6 +251,74 @@ def predict_boundary(model, batch, frames=512):
     return res
 
 
+def setup_clips(workload, model, per_gpu, world, rank, args, load_tune=None, save_tune=None):
+    """Frame-sharded clip workload: frame stage on T/world frames of every clip -> ONE all-gather -> replicated head."""
+    import torch
+    from deephar_amd import parallel
+    wl = WORKLOADS[workload]
+    T = wl['T']
+    clips = per_gpu * world
+    scm = parallel.ShardedClipModel(model, rank=rank, world=world)
+    fm, hm, info = scm.frame_model, scm.head_model, scm.info
+    for mm in (fm, hm):
+        mm.executor.use_graph = not args.no_graph
+        if load_tune:
+            load_tune(mm.executor)
+    x = np.random.default_rng(1234 + rank).uniform(-1, 1, (clips, info['Tl'], 256, 256, 3)).astype(np.float32)
+    x_dev = torch.from_numpy(x).to(fm.executor.device)          # this rank's frames, resident in HBM
+    pairs = []
+
+    def step():
+        ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+        pairs.append(ev)
+        scm.forward_device(x_dev, events=ev)
+
+    step()                                                      # binds / tunes both stages
+    pairs.clear()
+    if save_tune:
+        save_tune([fm.executor.tune_table, hm.executor.tune_table])
+    fbp = fm.executor.bound[clips]
+    hbp = hm.executor.bound[clips]
+    bound = [(fbp, fm.executor.stream_ptr), (hbp, hm.executor.stream_ptr)]
+    streams = [fm.executor.stream, hm.executor.stream]
+    flops = fm.plan.total_flops(clips) + hm.plan.total_flops(clips)
+    check = lambda: scm.last_outputs[0].cpu().numpy()
+    parallelism = 'frame-shard x%d: T/%d frames of %d clips per rank, one packed all-gather [%d, %d, J, %d] fp32, ' \
+                  'head replicated' % (world, world, clips, clips, info['Tl'], info['packed_channels'])
+    return step, pairs, bound, streams, clips * T, flops, check, parallelism, (lambda: None)
+
+
+def timed(step, streams, steps, warmup, world, pairs=None):
+    """W untimed steps, then exactly K steps bracketed by barrier + device synchronisation; max over ranks."""
+    import torch
+    import torch.distributed as dist
+
+    def drain():
+        for s_ in streams:
+            s_.synchronize()
+        torch.cuda.synchronize()
+
+    for _ in range(warmup):
+        step()
+    drain()
+    if pairs is not None:
+        pairs.clear()
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    drain()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device='cuda')
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    return dt
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -261,6 +329,8 @@ def main():
     ap.add_argument('--blocks', type=int, default=8, help='mpii only')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-predict', action='store_true', help='skip the Model.predict boundary measurement')
+    ap.add_argument('--no-clip-leg', action='store_true',
+                    help='mpii: skip the short frame-sharded penn_merge run appended to the line')
     ap.add_argument('--no-graph', action='store_true', help='launch kernels eagerly instead of hipGraph replay')
     ap.add_argument('--dump-steps', default=None, help='write the per-kernel profile (JSON) to this path')
     ap.add_argument('--streams', type=int, default=None,
@@ -349,61 +419,12 @@ def main():
         flops_per_step = plan.total_flops(n)
         check = lambda: bp.tensor(plan.outputs[-2]).cpu().numpy()
         parallelism = 'frame-shard x%d (replicas, no collective)' % world
+        pairs = None
     else:
-        # ---- clips: frame stage on T/world frames of every clip -> ONE all-gather -> replicated head ----------------
-        from deephar_amd import parallel
-        T = wl['T']
-        clips = per_gpu * world
-        scm = parallel.ShardedClipModel(model, rank=rank, world=world)
-        fm, hm, info = scm.frame_model, scm.head_model, scm.info
-        for mm in (fm, hm):
-            mm.executor.use_graph = not args.no_graph
-            load_tune(mm.executor)
-        x = np.random.default_rng(1234 + rank).uniform(-1, 1, (clips, info['Tl'], 256, 256, 3)).astype(np.float32)
-        x_dev = torch.from_numpy(x).to(fm.executor.device)          # this rank's frames, resident in HBM
-        ev = [torch.cuda.Event(enable_timing=True) for _ in range(2 * (args.steps + args.warmup + 4))]
-        pairs = []
+        (step, pairs, bound, streams, frames_per_step, flops_per_step, check, parallelism, restage) = \
+            setup_clips(args.workload, model, per_gpu, world, rank, args, load_tune, save_tune)
 
-        def step():
-            i = len(pairs)
-            pairs.append((ev[2 * i], ev[2 * i + 1]))
-            scm.forward_device(x_dev, events=pairs[-1])
-
-        step()                                                      # binds / tunes both stages
-        pairs.clear()
-        save_tune([fm.executor.tune_table, hm.executor.tune_table])
-        restage = lambda: None
-        fbp = fm.executor.bound[clips]
-        hbp = hm.executor.bound[clips]
-        bound = [(fbp, fm.executor.stream_ptr), (hbp, hm.executor.stream_ptr)]
-        streams = [fm.executor.stream, hm.executor.stream]
-        frames_per_step = clips * T
-        flops_per_step = fm.plan.total_flops(clips) + hm.plan.total_flops(clips)
-        check = lambda: scm.last_outputs[0].cpu().numpy()
-        parallelism = 'frame-shard x%d: T/%d frames of %d clips per rank, one packed all-gather [%d, %d, J, %d] fp32, ' \
-                      'head replicated' % (world, world, clips, clips, info['Tl'], info['packed_channels'])
-
-    def sync_all():
-        for s_ in streams:
-            s_.synchronize()
-        torch.cuda.synchronize()
-
-    for _ in range(args.warmup):
-        step()
-    sync_all()
-    if wl['clips']:
-        pairs.clear()
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    sync_all()
-    barrier()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device='cuda')
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    dt = timed(step, streams, args.steps, args.warmup, world, pairs)
     if wl['clips']:
         collective_us = round(1e3 * float(np.mean([a.elapsed_time(b) for a, b in pairs])), 2)
 
@@ -416,6 +437,20 @@ def main():
     rows, kinds = profile_plans(bound)
     ms_per_step = 1e3 * dt / args.steps
     roof, extra = roofline(rows, kinds, flops_per_step, ms_per_step)
+
+    # The default (mpii) line also carries a short run of the frame-sharded clip path, so that a multi-GPU run of the
+    # contract command exercises the RCCL all-gather leg as well (BASELINE.json configs[3]); every rank takes part.
+    clip_leg = None
+    if args.workload == 'mpii' and not args.no_clip_leg:
+        cw = WORKLOADS['penn_merge']
+        cstep, cpairs, _, cstreams, cframes, _, ccheck, cpar, _ = setup_clips('penn_merge', cw['build'](), cw['per_gpu'],
+                                                                             world, rank, args)
+        cdt = timed(cstep, cstreams, 10, 2, world, cpairs)
+        cpose = ccheck()
+        clip_leg = {'workload': cw['name'], 'value': round(cframes * 10 / cdt, 1), 'unit': 'frames/s',
+                    'steps': 10, 'ms_per_step': round(1e2 * cdt, 3), 'parallelism': cpar, 'rccl_ranks': world,
+                    'collective_us': round(1e3 * float(np.mean([a.elapsed_time(b) for a, b in cpairs])), 2),
+                    'outputs_finite_in_range': bool(np.all(np.isfinite(cpose)) and cpose.min() >= 0 and cpose.max() <= 1)}
 
     if rank == 0:
         out = {
@@ -443,6 +478,8 @@ def main():
         if collective_us is not None:
             out['collective_us'] = collective_us
             out['rccl_ranks'] = world
+        if clip_leg is not None:
+            out['frame_sharded_clips'] = clip_leg
         if args.workload == 'mpii' and world == 1 and not args.no_predict:
             fps = predict_boundary(model, per_gpu)
             out['predict_fps_f32'], out['predict_fps_u8'] = fps['f32'], fps['u8']

@@ -1,10 +1,13 @@
-"""Run one conv shape repeatedly (for rocprofv3 --pmc): python tools/bench_one.py H Cin Cout k stride cfg [reps]"""
+"""Run one conv shape repeatedly (for rocprofv3 --pmc):
+    python tools/bench_one.py H Cin Cout k stride cfg [reps] [pre_relu=1]
+BN + residual epilogue always on (the dominant GEMMs of the model carry both)."""
 import os, sys
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from deephar_amd import functional as F
 H, cin, cout, k, s, cfg = [int(v) for v in sys.argv[1:7]]
 reps = int(sys.argv[7]) if len(sys.argv) > 7 else 5
+relu = bool(int(sys.argv[8])) if len(sys.argv) > 8 else True
 dev = torch.device('cuda:0'); N = 64
 rng = np.random.default_rng(0)
 x = torch.randn(N, H, H, cin, device=dev)
@@ -14,5 +17,5 @@ oh = -(-H // s)
 qs, qb = torch.ones(cout, device=dev), torch.zeros(cout, device=dev)
 r1 = torch.randn(N, oh, oh, cout, device=dev)
 for _ in range(reps):
-    F.conv2d(x, w, (s, s), 'same', pre_relu=True, post_scale=qs, post_shift=qb, res1=r1, tile_cfg=cfg, packed=packed)
+    F.conv2d(x, w, (s, s), 'same', pre_relu=relu, post_scale=qs, post_shift=qb, res1=r1, tile_cfg=cfg, packed=packed)
 torch.cuda.synchronize()

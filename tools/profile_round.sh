@@ -1,11 +1,29 @@
-set -x
+#!/bin/bash
+# Round profile on the GPU box (gpurun): rocprofv3 kernel stats of the contract bench (1 and 2 graph branches) and PMC
+# passes (separate runs, one counter group each) of the dominant GEMM instantiations on the dominant shape.
+#   /usr/local/graft/bin/gpurun --timeout 1500 -- 'bash tools/profile_round.sh r02'
+# Summaries land in gpurun_out/<tag>_*; copy the ones to keep into profiles/.
+TAG=${1:-r02}
 cd $GRAFT_REPO_ROOT
-python bench.py --tune-cache gpurun_out/tune.json --no-cpu-baseline --steps 10 > gpurun_out/b0.log 2>&1
 export TMPDIR=/tmp
-(cd /tmp && rocprofv3 --kernel-trace --stats -d $GRAFT_REPO_ROOT/gpurun_out/prof_s2 -o out -- python $GRAFT_REPO_ROOT/bench.py --tune-cache $GRAFT_REPO_ROOT/gpurun_out/tune.json --no-cpu-baseline --steps 20 --warmup 3 > $GRAFT_REPO_ROOT/gpurun_out/prof_s2.log 2>&1)
-(cd /tmp && rocprofv3 --kernel-trace --stats -d $GRAFT_REPO_ROOT/gpurun_out/prof_s1 -o out -- python $GRAFT_REPO_ROOT/bench.py --tune-cache $GRAFT_REPO_ROOT/gpurun_out/tune.json --no-cpu-baseline --steps 20 --warmup 3 --streams 1 > $GRAFT_REPO_ROOT/gpurun_out/prof_s1.log 2>&1)
-for c in FETCH_SIZE WRITE_SIZE SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE; do
- (cd /tmp && rocprofv3 --pmc $c --kernel-trace -d $GRAFT_REPO_ROOT/gpurun_out/pmcf_$c -o out -- python $GRAFT_REPO_ROOT/tools/bench_one.py 32 576 576 1 1 11 4 > /dev/null 2>&1)
- (cd /tmp && rocprofv3 --pmc $c --kernel-trace -d $GRAFT_REPO_ROOT/gpurun_out/pmcg_$c -o out -- python $GRAFT_REPO_ROOT/tools/bench_one.py 32 576 576 1 1 12 4 > /dev/null 2>&1)
+OUT=$GRAFT_REPO_ROOT/gpurun_out
+B="--no-cpu-baseline --no-predict --no-clip-leg --tune-cache $OUT/${TAG}_tune.json"
+python bench.py $B --steps 10 > $OUT/${TAG}_b0.log 2>&1
+for S in 2 1; do
+  (cd /tmp && rocprofv3 --kernel-trace --stats -d $OUT/${TAG}_prof_s$S -o out -- python $GRAFT_REPO_ROOT/bench.py $B --steps 20 --warmup 3 --streams $S > $OUT/${TAG}_prof_s$S.log 2>&1)
+  DB=$(ls $OUT/${TAG}_prof_s$S/*/*results.db $OUT/${TAG}_prof_s$S/*results.db 2>/dev/null | head -1)
+  [ -n "$DB" ] && python tools/rocpd_stats.py kernels $DB $OUT/${TAG}_bench_kernel_stats_streams$S.csv
 done
-ls gpurun_out/prof_s2 gpurun_out/prof_s1 | head; tail -1 gpurun_out/prof_s2.log | cut -c1-300; tail -1 gpurun_out/prof_s1.log | cut -c1-300
+# PMC: gemm1x1 <4,1,1,3> (cfg 11) and <4,1,1,2> (cfg 12), pre_relu = 0 -> the <.., false, false, false> instantiations
+for CFG in 11 12; do
+ for C in FETCH_SIZE WRITE_SIZE SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE; do
+  (cd /tmp && rocprofv3 --pmc $C --kernel-trace -d $OUT/${TAG}_pmc_${CFG}_$C -o out -- python $GRAFT_REPO_ROOT/tools/bench_one.py 32 576 576 1 1 $CFG 4 0 > /dev/null 2>&1)
+  DB=$(ls $OUT/${TAG}_pmc_${CFG}_$C/*/*results.db $OUT/${TAG}_pmc_${CFG}_$C/*results.db 2>/dev/null | head -1)
+  [ -n "$DB" ] && python tools/rocpd_stats.py pmc $DB gemm1x1 >> $OUT/${TAG}_pmc_summary.txt
+ done
+done
+cat $OUT/${TAG}_pmc_summary.txt
+tail -1 $OUT/${TAG}_prof_s2.log | cut -c1-400
+head -12 $OUT/${TAG}_bench_kernel_stats_streams2.csv
+# keep the merged-back payload small
+rm -rf $OUT/${TAG}_prof_s1 $OUT/${TAG}_prof_s2 $OUT/${TAG}_pmc_1*
