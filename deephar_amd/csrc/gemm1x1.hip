@@ -41,11 +41,16 @@ __device__ __forceinline__ void lgkm_wait() {
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_sched_barrier(0);
 }
-// (an asm v_max_f32 would save the canonicalising max fmaxf implies, but hipcc pads no VALU->MFMA hazard
-// wait states after inline asm -- measured wrong results)
-__device__ __forceinline__ float4 relu4(float4 v) {
-  return make_float4(fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f));
+// ReLU as ONE integer instruction per element: non-negative floats order like non-negative ints and everything with
+// the sign bit set is a negative int, so max_i32(bits, 0) is relu(v) (-0 -> +0).  fmaxf costs two v_max_f32 (a
+// canonicalising one first), and on gfx950 nothing issues beside an fp32 MFMA (profiles/r02_sepconv_fusion_study.md):
+// every VALU instruction of the K loop is paid in full -- 32 instead of 16 per K-step was 4-8 % of the ReLU-on-load
+// GEMMs.  (An asm v_max_f32 is not an option: hipcc pads no VALU->MFMA hazard wait states after inline asm.)
+__device__ __forceinline__ float relu1(float v) {
+  const int b = __float_as_int(v);
+  return __int_as_float(b > 0 ? b : 0);
 }
+__device__ __forceinline__ float4 relu4(float4 v) { return make_float4(relu1(v.x), relu1(v.y), relu1(v.z), relu1(v.w)); }
 
 template <int TM, int TN, int BN, int BOFF, int S>
 __device__ __forceinline__ void fetch_frags(const unsigned (&a_addr)[TM][4], unsigned b_addr, float4 (&fa)[TM],

@@ -17,7 +17,12 @@ in the build container and committing the outputs (tests/golden/, scripts alongs
       (tests/test_reference_golden.py), and the HIP engine is tested against the same vectors;
   (2) the NumPy-only modules run as they are: soft-argmax grids (utils/math.py) bit-exact, affine / camera
       post-processing, metrics, pose-layout tables (tests/test_golden_host.py).
-What stays UNPINNED (restated from the Keras 2.1.4 / TF 1.6 defaults of SURVEY.md A.3, checked only by analytic
-known answers in tests/test_oracle_ops.py and an independent NumPy-fp64 decoder): the numerics inside the
-Keras layers themselves -- TF-"SAME" padding, BatchNormalization epsilon, pooling / up-sampling semantics.
+What stays UNPINNED (restated from the Keras 2.1.4 / TF 1.6 defaults of SURVEY.md A.3): the numerics inside the
+Keras layers themselves -- TF-"SAME" padding, BatchNormalization epsilon, pooling / up-sampling semantics.  They are
+checked three ways that do not involve Keras: analytic known answers (tests/test_oracle_ops.py), an independent
+NumPy-fp64 decoder, and -- so that this module and the mini-Keras stand-in (same author, same torch back-end) are not
+each other's only witness -- plain NumPy float64 LOOP implementations of conv / separable conv / max-pool / max-min
+pool / up-sampling / BatchNormalization written from the TensorFlow op documentation
+(tests/test_oracle_ops.py::test_layer_semantics_against_independent_numpy_loops).  The kit that closes the gap with the
+real Keras is tools/make_keras_parity_kit.py (needs a machine with keras==2.1.4 + tensorflow==1.6).
 """

@@ -171,3 +171,92 @@ def test_torch_oracle_agrees_with_numpy_fp64_decoder():
     np.testing.assert_allclose(ops.joints_probability(t).numpy()[..., 0], conf_np, rtol=1e-5, atol=1e-5)
     t64 = t.double()
     np.testing.assert_allclose(ops.softargmax2d(t64).numpy(), xy_np, atol=1e-12)
+
+
+O = ops
+
+
+# ---- an implementation of the Keras layer semantics that shares NOTHING with oracle/ops.py or mini-keras ----------------
+# oracle/ops.py and oracle/refrun/minikeras.py are both written on torch.nn.functional by the same author, so agreement
+# between them does not pin what Keras 2.1.4 / TF 1.6 decide inside a layer.  These are plain NumPy float64
+# loops written from the TensorFlow documentation of each op: 'SAME' padding = ceil(in / stride) outputs,
+# total padding (out - 1) * stride + k - in, the ODD cell goes to the bottom / right; max-pool ignores padding cells;
+# UpSampling2D repeats rows and columns; BatchNormalization inference = gamma * (x - mean) / sqrt(var + 1e-3) + beta;
+# SeparableConv2D = depthwise (per-channel) then 1x1, no activation between.
+def _np_same(n, k, s):
+    out = -(-n // s)
+    tot = max((out - 1) * s + k - n, 0)
+    return tot // 2, out
+
+
+def _np_conv2d_same(x, w, s):
+    n, h, wd, cin = x.shape
+    kh, kw, _, cout = w.shape
+    pt, oh = _np_same(h, kh, s)
+    pl, ow = _np_same(wd, kw, s)
+    y = np.zeros((n, oh, ow, cout))
+    for b in range(n):
+        for i in range(oh):
+            for j in range(ow):
+                for a in range(kh):
+                    for c in range(kw):
+                        ii, jj = i * s - pt + a, j * s - pl + c
+                        if 0 <= ii < h and 0 <= jj < wd:
+                            y[b, i, j] += x[b, ii, jj] @ w[a, c]
+    return y
+
+
+def _np_depthwise_same(x, w):
+    n, h, wd, ch = x.shape
+    kh, kw = w.shape[:2]
+    pt, _ = _np_same(h, kh, 1)
+    pl, _ = _np_same(wd, kw, 1)
+    y = np.zeros_like(x)
+    for i in range(h):
+        for j in range(wd):
+            for a in range(kh):
+                for c in range(kw):
+                    ii, jj = i - pt + a, j - pl + c
+                    if 0 <= ii < h and 0 <= jj < wd:
+                        y[:, i, j] += x[:, ii, jj] * w[a, c, :, 0]
+    return y
+
+
+def _np_maxpool_same(x, k, s):
+    n, h, wd, ch = x.shape
+    pt, oh = _np_same(h, k, s)
+    pl, ow = _np_same(wd, k, s)
+    y = np.full((n, oh, ow, ch), -np.inf)
+    for i in range(oh):
+        for j in range(ow):
+            for a in range(k):
+                for c in range(k):
+                    ii, jj = i * s - pt + a, j * s - pl + c
+                    if 0 <= ii < h and 0 <= jj < wd:
+                        y[:, i, j] = np.maximum(y[:, i, j], x[:, ii, jj])
+    return y
+
+
+@pytest.mark.parametrize('h,w,k,s', [(9, 8, 3, 2), (8, 8, 5, 1), (7, 10, 7, 2), (6, 6, 1, 1), (5, 9, 3, 1), (8, 6, 2, 2)])
+def test_layer_semantics_against_independent_numpy_loops(h, w, k, s):
+    rng = np.random.default_rng(h * 100 + w * 10 + k + s)
+    x = rng.standard_normal((2, h, w, 3))
+    wt = rng.standard_normal((k, k, 3, 4))
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a))
+    np.testing.assert_allclose(O.conv2d(t(x), t(wt), (s, s), 'same').numpy(), _np_conv2d_same(x, wt, s), atol=1e-12)
+    if s == 1:
+        dw = rng.standard_normal((k, k, 3, 1))
+        pw = rng.standard_normal((1, 1, 3, 5))
+        want = _np_conv2d_same(_np_depthwise_same(x, dw), pw, 1)
+        np.testing.assert_allclose(O.sepconv2d(t(x), t(dw), t(pw)).numpy(), want, atol=1e-12)
+    if k in (2, 3):
+        np.testing.assert_array_equal(O.maxpool2d(t(x), (k, k), (s, s), 'same').numpy(), _np_maxpool_same(x, k, s))
+        mm = _np_maxpool_same(x, 2, 2) - _np_maxpool_same(-x, 2, 2)      # layers.max_min_pooling: max(x) - max(-x)
+        np.testing.assert_allclose(O.max_min_pooling(t(x)).numpy(), mm, atol=0)
+    up = np.repeat(np.repeat(x, 2, axis=1), 2, axis=2)
+    np.testing.assert_array_equal(O.upsample2d(t(x)).numpy(), up)
+    beta, mean, var, gamma = (rng.standard_normal(3), rng.standard_normal(3), rng.uniform(0.5, 2, 3), rng.uniform(0.5, 2, 3))
+    bn = gamma * (x - mean) / np.sqrt(var + 1e-3) + beta
+    np.testing.assert_allclose(O.batchnorm(t(x), t(beta), t(mean), t(var), gamma=t(gamma)).numpy(), bn, atol=1e-12)
+    bn0 = (x - mean) / np.sqrt(var + 1e-3) + beta                         # layers.py BatchNormalization(scale=False)
+    np.testing.assert_allclose(O.batchnorm(t(x), t(beta), t(mean), t(var)).numpy(), bn0, atol=1e-12)
