@@ -18,7 +18,7 @@ class ConvArgs(C.Structure):
                                    'res1', 'res2', 'in_lut')] + \
                [(n, i32) for n in ('N', 'H', 'W', 'Cin', 'ldx', 'OH', 'OW', 'Cout', 'ldy', 'KH', 'KW', 'SH',
                                    'SW', 'PT', 'PL', 'K', 'Kp', 'Np', 'ldr1', 'ldr2', 'pre_relu', 'post_relu',
-                                   'up2', 'x_u8')]
+                                   'up2', 'x_u8', 'w_split')]
 
 
 class SepConvArgs(C.Structure):
@@ -55,6 +55,7 @@ SIGNATURES = {
     'dh_device_info': (C.c_int, [C.c_int, C.c_char_p, C.c_int, C.POINTER(C.c_int)]),
     'dh_conv2d_packed_dims': (C.c_int, [C.c_int] * 4 + [C.POINTER(C.c_int)] * 2),
     'dh_conv2d_pack_weights_host': (C.c_int, [vp, vp] + [C.c_int] * 4),
+    'dh_conv2d_pack_weights_split_host': (C.c_int, [vp, vp] + [C.c_int] * 4),
     'dh_conv2d_num_tile_cfgs': (C.c_int, []),
     'dh_conv2d_pick_tile_cfg': (C.c_int, [C.c_int, C.c_int]),
     'dh_conv2d_f32': (C.c_int, [C.POINTER(ConvArgs), C.c_int, vp]),

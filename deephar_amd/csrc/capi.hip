@@ -57,6 +57,42 @@ int dh_conv2d_pack_weights_host(const float* w, float* packed, int KH, int KW, i
   return DH_OK;
 }
 
+static inline uint16_t bf16_rne(float f) {
+  uint32_t u;
+  memcpy(&u, &f, 4);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (uint16_t)(u >> 16);
+}
+static inline float bf16_to_f(uint16_t h) {
+  const uint32_t u = (uint32_t)h << 16;
+  float f;
+  memcpy(&f, &u, 4);
+  return f;
+}
+
+int dh_conv2d_pack_weights_split_host(const float* w, uint16_t* packed, int KH, int KW, int Cin, int Cout) {
+  int Kp, Np;
+  if (w == nullptr || packed == nullptr || dh_conv2d_packed_dims(KH, KW, Cin, Cout, &Kp, &Np) != DH_OK)
+    return DH_EINVAL;
+  const int K = KH * KW * Cin;
+  memset(packed, 0, sizeof(uint16_t) * (size_t)3 * Kp * Np);
+  // unit (kg, part, n) = 8 bf16 at ((kg * 3 + part) * Np + n) * 8; element k % 8 inside
+  for (int k = 0; k < K; ++k)
+    for (int n = 0; n < Cout; ++n) {
+      const float x = w[(size_t)k * Cout + n];
+      const uint16_t h1 = bf16_rne(x);
+      const float r1 = x - bf16_to_f(h1);
+      const uint16_t h2 = bf16_rne(r1);
+      const float r2 = r1 - bf16_to_f(h2);
+      const uint16_t h3 = bf16_rne(r2);
+      const size_t base = ((size_t)(k >> 3) * 3 * Np + n) * 8 + (k & 7);
+      packed[base] = h1;
+      packed[base + (size_t)Np * 8] = h2;
+      packed[base + (size_t)2 * Np * 8] = h3;
+    }
+  return DH_OK;
+}
+
 int dh_conv2d_num_tile_cfgs(void) { return conv_igemm_num_cfgs(); }
 int dh_conv2d_pick_tile_cfg(int M, int Cout) { return conv_igemm_pick_cfg(M, Cout); }
 

@@ -275,6 +275,7 @@ int launch_cfg(const ConvArgs& a, bool vec4, int epi, hipStream_t s) {
 
 bool gemm1x1_eligible(const ConvArgs& a);
 int launch_gemm1x1(const ConvArgs& a, int cfg, int epi, hipStream_t s);
+int launch_gemm1x1_split(const ConvArgs& a, int cfg, int epi, hipStream_t s);
 
 // cfg 0..8: general implicit-GEMM kernel; cfg 9..17: the same tile shapes on the LDS-DMA pointwise kernel
 int conv_igemm_num_cfgs() { return 2 * kNumCfgs; }
@@ -311,6 +312,12 @@ int launch_conv_igemm(const ConvArgs& a, int cfg, hipStream_t s) {
                   (a.res1 == nullptr || (a.ldr1 % 4 == 0 && al16(a.res1))) &&
                   (a.res2 == nullptr || (a.ldr2 % 4 == 0 && al16(a.res2))) &&
                   (a.post_scale == nullptr || (al16(a.post_scale) && al16(a.post_shift)));
+  if (a.w_split) {                       // split-bf16 weights: only the LDS-DMA GEMM family reads that packing
+    if (a.x_u8 || !gemm1x1_eligible(a)) return DH_EUNSUPPORTED;
+    cfg %= kNumCfgs;
+    if (a.up2 && cfg == 0) cfg = 2;
+    return launch_gemm1x1_split(a, cfg, epi, s);
+  }
   if (cfg >= kNumCfgs) {
     cfg -= kNumCfgs;
     if (a.up2 && cfg == 0) cfg = 2;

@@ -42,16 +42,18 @@ class WeightStore:
                                'deephar_amd.weights.init_synthetic(model) before predict' % p.key)
         return p.value
 
-    def conv_weight(self, p):
-        ent = self.conv.get(id(p))
+    def conv_weight(self, p, split=False):
+        """split=True: the split-bf16 packing of dh_conv_args.w_split (kept next to the fp32 packing when both are in use)."""
+        key = (id(p), bool(split))
+        ent = self.conv.get(key)
         if ent is None or ent[3] != p.version:
-            packed, kp, np_ = packing.pack_conv(self._require(p))
+            packed, kp, np_ = (packing.pack_conv_split if split else packing.pack_conv)(self._require(p))
             if ent is None:
                 ent = (self._dev(packed), kp, np_, p.version)
             else:
                 ent[0].copy_(self._dev(packed))
                 ent = (ent[0], kp, np_, p.version)
-            self.conv[id(p)] = ent
+            self.conv[key] = ent
         return ent[0], ent[1], ent[2]
 
     def dw_weight(self, p):
@@ -175,6 +177,25 @@ class BoundPlan:
         for step in plan.steps:
             self._bind(step)
 
+    def split_ok(self, s):
+        """Does this conv step run on the bf16 matrix cores (plan.gemm_precision == 'bf16x3')?  Mirrors gemm1x1_eligible
+        (gemm1x1.hip): LDS-DMA GEMM shapes only -- pointwise, or K x K with Cin % 32 == 0 and no fused up-sampling;
+        16-byte aligned input view; no BatchNorm prologue; float input."""
+        if getattr(self.plan, 'gemm_precision', 'f32') != 'bf16x3' or 'pre_bn' in s.params:
+            return False
+        a, x = s.attrs, s.ins['x']
+        if x.ld % 4 or x.coff % 4:
+            return False
+        if self.u8 is not None and id(x.buf) in self.u8 and self.u8[id(x.buf)][2]:
+            return False
+        y = s.outs['y']
+        up = 2 if a['up2'] else 1
+        same = x.shape[-3] == y.shape[-3] // up and x.shape[-2] == y.shape[-2] // up
+        pointwise = a['kh'] == a['kw'] == 1 and a['sh'] == a['sw'] == 1 and a['pt'] == a['pl'] == 0 and same and \
+            a['Cin'] % 4 == 0
+        kxk = a['Cin'] % 32 == 0 and not a['up2']
+        return pointwise or kxk
+
     # ---- views -------------------------------------------------------------------------------------------
     def ptr(self, v):
         return self.base + 4 * (v.buf.offset * self.n + v.coff)
@@ -203,7 +224,8 @@ class BoundPlan:
 
         if k in ('conv', 'sepconv'):
             x, y = s.ins['x'], s.outs['y']
-            wt, kp, np_ = self.store.conv_weight(s.params['w'])
+            split = k == 'conv' and self.split_ok(s)
+            wt, kp, np_ = self.store.conv_weight(s.params['w'], split=split)
             sep = _lib.SepConvArgs() if k == 'sepconv' else None
             args = sep.pw if sep is not None else _lib.ConvArgs()
             args.x, args.w, args.y = P(x), wt.data_ptr(), P(y)
@@ -225,6 +247,7 @@ class BoundPlan:
             if r2 is not None:
                 args.res2, args.ldr2 = P(r2), r2.ld
             args.pre_relu, args.post_relu, args.up2 = a['pre_relu'], a['post_relu'], a['up2']
+            args.w_split = int(split)
             if self.u8 is not None and id(x.buf) in self.u8 and self.u8[id(x.buf)][2]:
                 buf, lut, _ = self.u8[id(x.buf)]
                 args.x, args.in_lut, args.x_u8 = buf.data_ptr(), lut.data_ptr(), 1
@@ -459,7 +482,10 @@ class BoundPlan:
                 continue
             ncfg = ncfgs[step.kind]
             cargs = args[0]._obj.pw if step.kind == 'sepconv' else args[0]._obj
-            sig = (self.n, step.kind) + self._conv_signature(step) + ((('u8',) if cargs.x_u8 else ()))
+            sig = (self.n, step.kind) + self._conv_signature(step) + ((('u8',) if cargs.x_u8 else ())) + \
+                ((('bf16x3',) if cargs.w_split else ()))
+            if cargs.w_split:
+                ncfg = 9                                    # the split kernels exist in the 9 GEMM tile shapes only
             if sig not in table:
                 best, best_ms = -1, float('inf')
                 for cfg in range(ncfg):
@@ -598,8 +624,11 @@ class Executor:
         with torch.cuda.device(self.device), torch.cuda.stream(self.stream):
             for s in self.plan.steps:
                 for role, p in s.params.items():
-                    if role == 'w':
-                        (self.store.dw_weight if s.kind == 'dwconv' else self.store.conv_weight)(p)
+                    if role == 'w' and s.kind != 'dwconv':
+                        for (pid, split) in [k_ for k_ in self.store.conv if k_[0] == id(p)]:
+                            self.store.conv_weight(p, split=split)
+                    elif role == 'w':
+                        self.store.dw_weight(p)
                     elif role == 'dw':
                         self.store.dw_weight(p)
                     else:

@@ -104,6 +104,7 @@ class Plan:
         self.out_items = 0     # the model outputs occupy [0, out_items) of it (schedule.allocate)
         self.params = []       # ordered unique graph.Param list
         self.nstreams = 1
+        self.gemm_precision = 'f32'   # 'bf16x3': eligible convs run split-bf16 on the bf16 matrix cores (executor)
 
     def total_flops(self, n=1):
         return sum(s.flops(n) for s in self.steps)
@@ -604,5 +605,9 @@ class Planner:
         self.plan.params = out
 
 
-def build_plan(inputs, outputs, nstreams=1, fuse_sepconv=None):
-    return Planner(inputs, outputs, nstreams, fuse_sepconv).run()
+def build_plan(inputs, outputs, nstreams=1, fuse_sepconv=None, gemm_precision='f32'):
+    if gemm_precision not in ('f32', 'bf16x3'):
+        raise ValueError("gemm_precision must be 'f32' or 'bf16x3', got %r" % (gemm_precision,))
+    plan = Planner(inputs, outputs, nstreams, fuse_sepconv).run()
+    plan.gemm_precision = gemm_precision
+    return plan

@@ -42,6 +42,10 @@ class Model:
         # on the host (utils/transform.normalize_channels(frame, channel_power), transform.py:212-231)
         self.channel_power = 1
         self.fuse_sepconv = None      # None: DEEPHAR_FUSE_SEPCONV (default off); see engine/planner.py R6
+        # 'f32' (default): every conv on the fp32 matrix path, an exact k-ordered fmaf chain.  'bf16x3': pointwise / K x K
+        # GEMM-shaped convs split their fp32 operands exactly into three bf16 parts and run six partial products on the
+        # bf16 matrix cores with fp32 accumulation (csrc/gemm1x1s.hip): same accuracy class, ~1.7x faster, not bit-identical
+        self.gemm_precision = __import__('os').environ.get('DEEPHAR_GEMM', 'f32')
         # validates connectivity early (raises like Keras' "graph disconnected")
         self._nodes = G.topo_nodes(self.outputs)
         reach = {t.uid for t in self.inputs}
@@ -170,7 +174,7 @@ class Model:
         if self._plan is None:
             from .engine.planner import build_plan
             self._plan = build_plan(self.inputs, self.outputs, nstreams=self.num_streams,
-                                    fuse_sepconv=self.fuse_sepconv)
+                                    fuse_sepconv=self.fuse_sepconv, gemm_precision=self.gemm_precision)
         return self._plan
 
     @property

@@ -69,6 +69,12 @@ typedef struct dh_conv_args {
                    BN prologue, zero padding is applied after it.  This is utils/transform.normalize_channels
                    (transform.py:212-231: /255, power, -0.5, *2 in float32) fused into the first convolution; only
                    the general K x K path takes it (Cin % 4 != 0 or tile_cfg < dh_conv2d_num_tile_cfgs()/2) */
+  int32_t w_split; /* 1: `w` was packed by dh_conv2d_pack_weights_split_host (every weight split exactly into three bf16
+                      parts) and the convolution runs on the bf16 matrix cores: fp32 activations are split the same way
+                      on the fly, six of the nine partial products are accumulated in fp32 (gemm1x1s.hip).  Same
+                      inputs / outputs / epilogue; per-product error <= 2^-23 relative, i.e. below the rounding of the
+                      fp32 accumulation -- NOT bit-identical to w_split = 0.  Only shapes the LDS-DMA GEMM covers
+                      (pointwise, or K x K with Cin % 32 == 0; 16-byte aligned x; no BN prologue), else DH_EUNSUPPORTED */
 } dh_conv_args;
 
 /* padded dims of the packed weight for a [KH,KW,Cin,Cout] (Keras HWIO) kernel */
@@ -76,6 +82,10 @@ int dh_conv2d_packed_dims(int KH, int KW, int Cin, int Cout, int* Kp, int* Np);
 /* host-side repack HWIO -> [Kp/4][Np][4]; `packed_host` holds Kp*Np floats */
 int dh_conv2d_pack_weights_host(const float* w_hwio_host, float* packed_host, int KH, int KW, int Cin,
                                 int Cout);
+/* split packing for w_split = 1: `packed_host` holds 3 * Kp * Np uint16 (bf16 bit patterns) laid out
+ * [Kp/8][3 parts][Np][8]; same Kp / Np as dh_conv2d_packed_dims */
+int dh_conv2d_pack_weights_split_host(const float* w_hwio_host, uint16_t* packed_host, int KH, int KW, int Cin,
+                                      int Cout);
 /* tile_cfg < 0: library heuristic; 0..dh_conv2d_num_tile_cfgs()-1 forces a tiling (autotuning hook) */
 int dh_conv2d_num_tile_cfgs(void);
 int dh_conv2d_pick_tile_cfg(int M, int Cout);

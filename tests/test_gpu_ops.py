@@ -423,3 +423,67 @@ def test_sepconv_fused_frames_do_not_leak(hip_lib, cuda):
     b = F.sepconv2d(d(x2), dw, pw, pre_relu=True)
     torch.cuda.synchronize()
     assert torch.equal(a[0], b[0]) and torch.equal(a[2], b[2]) and not torch.equal(a[1], b[1])
+
+
+# ---- split-bf16 GEMM (dh_conv_args.w_split, gemm1x1s.hip) --------------------------------------------------------------
+SPLIT_CASES = [
+    # (N, H, W, Cin, Cout, k, stride, relu, residual, up2)
+    (2, 32, 32, 576, 576, 1, 1, True, True, False),      # the dominant pointwise GEMM
+    (3, 16, 16, 288, 288, 1, 1, False, True, False),
+    (2, 32, 32, 576, 48, 1, 1, True, False, False),      # RegMap: ragged Cout
+    (2, 32, 32, 48, 576, 1, 1, True, False, False),      # fReMap: K = 48 (padded to 64)
+    (2, 16, 16, 288, 576, 1, 1, False, True, True),      # fused up-sampling epilogue
+    (2, 33, 31, 64, 96, 3, 1, True, False, False),       # K x K through the zero-page DMA, ragged M
+    (1, 32, 32, 64, 96, 3, 2, False, False, False),      # strided
+    (2, 19, 23, 96, 200, 1, 1, True, True, False),       # ragged everywhere
+]
+
+
+@pytest.mark.parametrize('case', SPLIT_CASES)
+def test_conv2d_split_bf16(case, hip_lib, cuda):
+    """Split-bf16 convolution: (a) as close to the fp64 truth as the fp32-MFMA path (the six-product split loses less
+    than the fp32 accumulation does), (b) every tiling bit-identical to every other (same K order)."""
+    from deephar_amd import functional as F
+    n, h, w, cin, cout, ks, st, relu, res, up2 = case
+    rng = np.random.default_rng(sum(int(v) for v in case))
+    x = _rand(rng, (n, h, w, cin))
+    k = _rand(rng, (ks, ks, cin, cout), np.sqrt(1.0 / (ks * ks * cin)))
+    sc = rng.uniform(0.5, 1.5, cout).astype(np.float32)
+    sh = _rand(rng, (cout,), 0.1)
+    oh, ow = -(-h // st), -(-w // st)
+    r1 = _rand(rng, (n, oh, ow, cout)) if res else None
+    r2 = _rand(rng, (n, 2 * oh, 2 * ow, cout)) if up2 else None
+    t = lambda a: torch.from_numpy(a).double()
+    xin = O.relu(t(x)) if relu else t(x)
+    ref = O.conv2d(xin, t(k), (st, st), 'same') * t(sc) + t(sh)
+    if res:
+        ref = ref + t(r1)
+    if up2:
+        ref = O.upsample2d(ref) + t(r2)
+    d = lambda a: None if a is None else torch.from_numpy(a).to(cuda)
+    kw = dict(strides=(st, st), padding='same', pre_relu=relu, post_scale=d(sc), post_shift=d(sh), res1=d(r1), res2=d(r2),
+              up2=up2)
+    f32 = F.conv2d(d(x), k, **kw)
+    outs = {}
+    for cfg in range(-1, 9):
+        try:
+            outs[cfg] = F.conv2d(d(x), k, split=True, tile_cfg=cfg, **kw)
+        except Exception as e:
+            assert 'rc=-2' in str(e), e
+    torch.cuda.synchronize()
+    assert len(outs) >= 3
+    first = next(iter(outs.values()))
+    for cfg, y in outs.items():
+        assert torch.equal(y, first), 'split tiling %d differs' % cfg
+    e_split = (first.cpu().double() - ref).abs().max().item()
+    e_f32 = (f32.cpu().double() - ref).abs().max().item()
+    print('case %s: |split - fp64| = %.3e   |fp32 mfma - fp64| = %.3e' % (case, e_split, e_f32))
+    assert e_split <= 2.0 * e_f32 + 1e-6, (e_split, e_f32)
+
+
+def test_conv2d_split_rejects_what_the_gemm_family_cannot_run(hip_lib, cuda):
+    from deephar_amd import functional as F
+    from deephar_amd._lib import DeepharHipError
+    x = torch.randn(1, 16, 16, 3, device=cuda)                      # Cin = 3: general implicit-GEMM kernel only
+    with pytest.raises(DeepharHipError):
+        F.conv2d(x, np.zeros((3, 3, 3, 32), np.float32), split=True)
