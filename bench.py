@@ -152,6 +152,9 @@ def kernel_name(s):
     t = TILES[cfg % 9]
     b = lambda v: 'true' if v else 'false'
     a = s.attrs
+    if a.get('w_split'):
+        kxk = not (a['kh'] == a['kw'] == 1 and a['sh'] == a['sw'] == 1 and a['pt'] == a['pl'] == 0)
+        return 'gemm1x1s_kernel<%d, %d, %d, %d, %s, %s, %s>' % (t + (b(a['up2']), b(a['pre_relu']), b(kxk)))
     if cfg >= 9:
         kxk = not (a['kh'] == a['kw'] == 1 and a['sh'] == a['sw'] == 1 and a['pt'] == a['pl'] == 0)
         return 'gemm1x1_kernel<%d, %d, %d, %d, %s, %s, %s>' % (t + (b(a['up2']), b(a['pre_relu']), b(kxk)))
@@ -329,6 +332,9 @@ def main():
     ap.add_argument('--blocks', type=int, default=8, help='mpii only')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-predict', action='store_true', help='skip the Model.predict boundary measurement')
+    ap.add_argument('--gemm', choices=('f32', 'bf16x3'), default=None,
+                    help='GEMM arithmetic of the measured model (default: the product default, f32 = fp32 MFMA)')
+    ap.add_argument('--no-bf16x3', action='store_true', help='mpii: skip the split-bf16 leg appended to the line')
     ap.add_argument('--no-clip-leg', action='store_true',
                     help='mpii: skip the short frame-sharded penn_merge run appended to the line')
     ap.add_argument('--no-graph', action='store_true', help='launch kernels eagerly instead of hipGraph replay')
@@ -367,6 +373,8 @@ def main():
     model = wl['build'](args.blocks) if args.workload == 'mpii' else wl['build']()
     if args.streams is not None:
         model.num_streams = args.streams
+    if args.gemm is not None:
+        model.gemm_precision = args.gemm
 
     def load_tune(ex):
         if args.tune_cache and os.path.exists(args.tune_cache):
@@ -383,14 +391,16 @@ def main():
                 json.dump({json.dumps(list(k)): v for k, v in merged.items()}, f)
 
     collective_us = None
-    if not wl['clips']:
-        # ---- frames: replicas, no collective ---------------------------------------------------------------------
+    def setup_frames(model, tune=True):
+        """Replicas, no collective: batch resident in HBM (plus a second resident copy to re-stage from)."""
         plan, ex, n = model.plan, model.executor, per_gpu
         ex.use_graph = not args.no_graph
-        load_tune(ex)
+        if tune:
+            load_tune(ex)
         u8 = args.input == 'u8'
         bp = ex.bind(n, u8_norm=1 if u8 else None)
-        save_tune([ex.tune_table])
+        if tune:
+            save_tune([ex.tune_table])
         if u8:
             x = np.random.default_rng(1234 + rank).integers(0, 256, (n, 256, 256, 3), dtype=np.uint8)
         else:
@@ -413,11 +423,11 @@ def main():
                 if not u8:
                     bp.tensor(plan.inputs[0]).copy_(x_dev)
 
-        bound = [(bp, ex.stream_ptr)]
-        streams = [ex.stream]
-        frames_per_step = world * n
-        flops_per_step = plan.total_flops(n)
         check = lambda: bp.tensor(plan.outputs[-2]).cpu().numpy()
+        return step, [(bp, ex.stream_ptr)], [ex.stream], world * n, plan.total_flops(n), check, restage
+
+    if not wl['clips']:
+        step, bound, streams, frames_per_step, flops_per_step, check, restage = setup_frames(model)
         parallelism = 'frame-shard x%d (replicas, no collective)' % world
         pairs = None
     else:
@@ -437,6 +447,41 @@ def main():
     rows, kinds = profile_plans(bound)
     ms_per_step = 1e3 * dt / args.steps
     roof, extra = roofline(rows, kinds, flops_per_step, ms_per_step)
+
+    # The default line also measures the opt-in split-bf16 GEMM mode (Model.gemm_precision = 'bf16x3'): same model, same
+    # batch, same timing; reported under "bf16x3", never as `value` (the headline stays on the fp32-MFMA path).
+    split_leg = None
+    if args.workload == 'mpii' and model.gemm_precision == 'f32' and not args.no_bf16x3:
+        sm = wl['build'](args.blocks)
+        sm.gemm_precision = 'bf16x3'
+        if args.streams is not None:
+            sm.num_streams = args.streams
+        sstep, sbound, sstreams, sframes, sflops, scheck, srestage = setup_frames(sm, tune=False)
+        sdt = timed(sstep, sstreams, args.steps, args.warmup, world, None)
+        spose = scheck()
+        srestage()
+        srows, skinds = profile_plans(sbound)
+        sroof, sextra = roofline(srows, skinds, sflops, 1e3 * sdt / args.steps)
+        # six bf16 MFMAs per 16 k-values of a 32x32 tile: the matrix-core ceiling in fp32-equivalent FLOP/s
+        sroof['peak'] = round(2500.0 / 6.0, 1)
+        sroof['peak_note'] = 'dense bf16 MFMA peak (2.5 PFLOP/s) / 6 partial products, in fp32-equivalent TFLOP/s'
+        for key in ('frac',):
+            sroof[key] = round(sroof['achieved'] / sroof['peak'], 4)
+        sroof['all_mfma_conv_kernels']['frac_of_fp32_mfma_peak'] = sroof['all_mfma_conv_kernels'].pop('frac')
+        sroof['whole_forward_frac_of_fp32_mfma_peak'] = sroof.pop('whole_forward_frac')
+        split_leg = {'value': round(sframes * args.steps / sdt, 1), 'unit': 'frames/s',
+                     'ms_per_step': round(1e3 * sdt / args.steps, 3), 'steps': args.steps,
+                     'dtype': 'f32 operands split exactly into 3 x bf16, 6 partial products on v_mfma_f32_32x32x16_bf16, '
+                              'fp32 accumulate (csrc/gemm1x1s.hip); first conv / BN-prologue convs stay on the fp32 path',
+                     'parity': 'same tests and tolerances as the default path: tests/test_gpu_bf16x3.py, '
+                               'profiles/parity_r02_bf16x3.json',
+                     'outputs_finite_in_range': bool(np.all(np.isfinite(spose)) and spose[..., :2].min() >= 0 and
+                                                     spose[..., :2].max() <= 1),
+                     'roofline': sroof, 'kernel_time_share': sextra['kernel_time_share']}
+        if world == 1 and not args.no_predict:
+            sfps = predict_boundary(sm, per_gpu)
+            split_leg['predict_fps_f32'], split_leg['predict_fps_u8'] = sfps['f32'], sfps['u8']
+        del sm
 
     # The default (mpii) line also carries a short run of the frame-sharded clip path, so that a multi-GPU run of the
     # contract command exercises the RCCL all-gather leg as well (BASELINE.json configs[3]); every rank takes part.
@@ -465,12 +510,13 @@ def main():
             'higher_is_better': True,
             'scaling': 'weak',
             'vs_baseline': None,
-            'dtype': 'f32',
+            'dtype': 'f32' if model.gemm_precision == 'f32' else 'f32 (operands split exactly into 3 x bf16, fp32 accumulate)',
             'data': 'synthetic',
             'config': {'workload': wl['name'] if args.workload != 'mpii' or (args.blocks == 8 and per_gpu == 64) else
                        'MPII single-person 256x256, ReceptionNet %d blocks, batch=%d per GPU' % (args.blocks, per_gpu),
                        'global_batch': per_gpu * world, 'frames_per_step': frames_per_step, 'parallelism': parallelism,
                        'hipgraph': not args.no_graph, 'streams': model.plan.nstreams, 'input': args.input,
+                       'gemm': model.gemm_precision,
                        'outputs_finite_in_range': ok},
             'roofline': roof,
         }
@@ -480,6 +526,8 @@ def main():
             out['rccl_ranks'] = world
         if clip_leg is not None:
             out['frame_sharded_clips'] = clip_leg
+        if split_leg is not None:
+            out['bf16x3'] = split_leg
         if args.workload == 'mpii' and world == 1 and not args.no_predict:
             fps = predict_boundary(model, per_gpu)
             out['predict_fps_f32'], out['predict_fps_u8'] = fps['f32'], fps['u8']

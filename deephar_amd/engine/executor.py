@@ -248,6 +248,7 @@ class BoundPlan:
                 args.res2, args.ldr2 = P(r2), r2.ld
             args.pre_relu, args.post_relu, args.up2 = a['pre_relu'], a['post_relu'], a['up2']
             args.w_split = int(split)
+            a['w_split'] = int(split)                  # (read by bench.py to name the kernel)
             if self.u8 is not None and id(x.buf) in self.u8 and self.u8[id(x.buf)][2]:
                 buf, lut, _ = self.u8[id(x.buf)]
                 args.x, args.in_lut, args.x_u8 = buf.data_ptr(), lut.data_ptr(), 1

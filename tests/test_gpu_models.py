@@ -459,11 +459,11 @@ def test_fused_sepconv_plan_is_bit_identical(hip_lib, cuda):
     from collections import Counter
     x = np.random.default_rng(9).uniform(-1, 1, (3, 256, 256, 3)).astype(np.float32)
     m, _ = _build(2, 2, 16, num_context_per_joint=2)
-    m.fuse_sepconv = False
+    m.fuse_sepconv, m.gemm_precision = False, 'f32'      # (the fused kernel is an fp32-MFMA kernel)
     ref = m.predict(x, batch_size=3)
     assert Counter(s.kind for s in m.plan.steps)['dwconv'] == 17
     f, _ = _build(2, 2, 16, num_context_per_joint=2)
-    f.fuse_sepconv = True
+    f.fuse_sepconv, f.gemm_precision = True, 'f32'
     kinds = Counter(s.kind for s in f.plan.steps)
     assert kinds['sepconv'] == 17 and kinds['dwconv'] == 0
     got = f.predict(x, batch_size=3)

@@ -7,7 +7,7 @@ TAG=${1:-r02}
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
 OUT=$GRAFT_REPO_ROOT/gpurun_out
-B="--no-cpu-baseline --no-predict --no-clip-leg --tune-cache $OUT/${TAG}_tune.json"
+B="--no-cpu-baseline --no-predict --no-clip-leg --no-bf16x3 --tune-cache $OUT/${TAG}_tune.json"
 python bench.py $B --steps 10 > $OUT/${TAG}_b0.log 2>&1
 for S in 2 1; do
   (cd /tmp && rocprofv3 --kernel-trace --stats -d $OUT/${TAG}_prof_s$S -o out -- python $GRAFT_REPO_ROOT/bench.py $B --steps 20 --warmup 3 --streams $S > $OUT/${TAG}_prof_s$S.log 2>&1)
