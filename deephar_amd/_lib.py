@@ -57,6 +57,7 @@ SIGNATURES = {
     'dh_conv2d_pack_weights_host': (C.c_int, [vp, vp] + [C.c_int] * 4),
     'dh_conv2d_pack_weights_split_host': (C.c_int, [vp, vp] + [C.c_int] * 4),
     'dh_conv2d_num_tile_cfgs': (C.c_int, []),
+    'dh_conv2d_num_split_tile_cfgs': (C.c_int, []),
     'dh_conv2d_pick_tile_cfg': (C.c_int, [C.c_int, C.c_int]),
     'dh_conv2d_f32': (C.c_int, [C.POINTER(ConvArgs), C.c_int, vp]),
     'dh_sepconv2d_num_tile_cfgs': (C.c_int, []),

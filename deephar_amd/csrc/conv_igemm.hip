@@ -276,6 +276,7 @@ int launch_cfg(const ConvArgs& a, bool vec4, int epi, hipStream_t s) {
 bool gemm1x1_eligible(const ConvArgs& a);
 int launch_gemm1x1(const ConvArgs& a, int cfg, int epi, hipStream_t s);
 int launch_gemm1x1_split(const ConvArgs& a, int cfg, int epi, hipStream_t s);
+int gemm1x1_split_num_cfgs();
 
 // cfg 0..8: general implicit-GEMM kernel; cfg 9..17: the same tile shapes on the LDS-DMA pointwise kernel
 int conv_igemm_num_cfgs() { return 2 * kNumCfgs; }
@@ -304,8 +305,8 @@ int launch_conv_igemm(const ConvArgs& a, int cfg, hipStream_t s) {
     return DH_EINVAL;
   if (a.x_u8 && a.in_lut == nullptr) return DH_EINVAL;
   if (cfg < 0)
-    cfg = conv_igemm_pick_cfg(a.N * a.OH * a.OW, a.Cout) + (!a.x_u8 && gemm1x1_eligible(a) ? kNumCfgs : 0);
-  if (cfg >= 2 * kNumCfgs) return DH_EINVAL;
+    cfg = conv_igemm_pick_cfg(a.N * a.OH * a.OW, a.Cout) + (!a.w_split && !a.x_u8 && gemm1x1_eligible(a) ? kNumCfgs : 0);
+  if (!a.w_split && cfg >= 2 * kNumCfgs) return DH_EINVAL;
   if (a.x_u8 && cfg >= kNumCfgs) return DH_EUNSUPPORTED;
   auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
   const int epi = (a.Cout % 4 == 0) && (a.ldy % 4 == 0) && al16(a.y) &&
@@ -314,7 +315,7 @@ int launch_conv_igemm(const ConvArgs& a, int cfg, hipStream_t s) {
                   (a.post_scale == nullptr || (al16(a.post_scale) && al16(a.post_shift)));
   if (a.w_split) {                       // split-bf16 weights: only the LDS-DMA GEMM family reads that packing
     if (a.x_u8 || !gemm1x1_eligible(a)) return DH_EUNSUPPORTED;
-    cfg %= kNumCfgs;
+    if (cfg >= gemm1x1_split_num_cfgs()) return DH_EINVAL;
     if (a.up2 && cfg == 0) cfg = 2;
     return launch_gemm1x1_split(a, cfg, epi, s);
   }

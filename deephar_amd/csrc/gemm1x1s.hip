@@ -20,13 +20,22 @@ namespace {
 
 constexpr int BK = 32;
 
-__device__ __attribute__((aligned(128))) float g_zero_page_s[BK] = {};
-
-typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// buffer_load_dwordx4 ... offen lds: 16 bytes per lane from (descriptor base + voff + soff) to LDS (wave-uniform `dst`
+// + lane * 16).  A 32-bit per-lane offset fixed over K plus a SCALAR K-step offset: no per-step 64-bit address VALU
+// (5.7 VALU per MFMA were measured in the first version of this kernel; about 4 hide under a bf16 MFMA).  An
+// out-of-range offset loads zeros.  The builtin only exists for the gfx950 pass (see sepconv_fused.hip).
+template <typename RSRC>
+__device__ __forceinline__ void dma16(RSRC rs, float* dst, unsigned voff, int soff) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lptr_t)dst, 16, voff, soff, 0, 0);
+#endif
+}
+constexpr unsigned OOB = 0xfffffff0u;
 
 template <int OFF>
 __device__ __forceinline__ float4 lds_rd(unsigned addr) {
@@ -88,26 +97,35 @@ __device__ __forceinline__ bf16x8 as_bf(float4 v) {
   return __builtin_bit_cast(bf16x8, (f32x4){v.x, v.y, v.z, v.w});
 }
 
-// six partial products, smallest first
-__device__ __forceinline__ void mfma6(const Frag3& a, const bf16x8 (&b)[3], f32x16& c) {
-  c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.p[2], b[0], c, 0, 0, 0);
-  c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.p[0], b[2], c, 0, 0, 0);
-  c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.p[1], b[1], c, 0, 0, 0);
-  c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.p[1], b[0], c, 0, 0, 0);
-  c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.p[0], b[1], c, 0, 0, 0);
-  c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.p[0], b[0], c, 0, 0, 0);
+// Six partial products, smallest first: (a part, b part) = (2,0) (0,2) (1,1) (1,0) (0,1) (0,0).  They are issued
+// product-major over all TM x TN tiles of the wave: consecutive MFMAs then write DIFFERENT accumulators.  Issued
+// tile-major (six dependent MFMAs on one accumulator back to back) every MFMA waits out its predecessor's result
+// latency, which is longer than the 32-cycle issue interval of v_mfma_f32_32x32x16_bf16 (measured: matrix pipe 42 % busy,
+// 56 % of the wave cycles in issue stalls).  The order per accumulator -- and with it every result bit -- is unchanged.
+template <int TM, int TN>
+__device__ __forceinline__ void mfma6_tiles(const Frag3 (&a)[TM], const bf16x8 (&b)[TN][3], f32x16 (&acc)[TM][TN]) {
+  constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
+#pragma unroll
+  for (int t = 0; t < 6; ++t)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i].p[PA[t]], b[j][PB[t]], acc[i][j], 0, 0, 0);
 }
 
-template <int WM, int WN, int TM, int TN, bool UP2, bool RELU, bool KXK = false>
-__global__ __launch_bounds__(WM* WN * 64, 2) void gemm1x1s_kernel(const ConvArgs p, const int epi_vec) {
+// NS = number of LDS stages: 2 (next K-step in flight) or 3 (two K-steps in flight: the split kernel's K-step is short
+// enough that one DMA round trip no longer fits under it).
+template <int WM, int WN, int TM, int TN, bool UP2, bool RELU, bool KXK = false, int NS = 2>
+__global__ __launch_bounds__(WM* WN * 64, WM * WN >= 8 ? 2 : 2) void gemm1x1s_kernel(const ConvArgs p, const int epi_vec) {
   constexpr int NT = WM * WN * 64;
   constexpr int BM = WM * TM * 32;
   constexpr int BN = WN * TN * 32;
   constexpr int APASS = BM * 8 / NT;
   constexpr int BPASS = (12 * BN + NT - 1) / NT;         // 16-byte units per thread: 4 k-groups x 3 parts x BN
-  constexpr int BROWS = BPASS * NT;                      // padded unit count of the B stage
+  constexpr int BROWS = 12 * BN;                         // 16-byte units of the B stage (the last pass is partial)
   constexpr int STAGE = BM * BK + BROWS * 4;             // floats per stage
-  static_assert(BM * 8 % NT == 0, "tile/thread mismatch");
+  static_assert(BM * 8 % NT == 0 && (12 * BN) % 64 == 0, "tile/thread mismatch");
 
   extern __shared__ __attribute__((aligned(16))) float smem[];
 
@@ -123,8 +141,13 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void gemm1x1s_kernel(const ConvArgs
   const int m0 = (tile / tiles_n) * BM;
   const int n0 = (tile % tiles_n) * BN;
 
-  // ---- per-thread DMA sources (as gemm1x1_kernel)
-  const float* a_src[APASS];
+  // ---- per-thread DMA sources: byte offsets into two buffer descriptors (activations, packed split weight)
+  const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+  const auto rs_x = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(p.x), 0, (int)(((unsigned)(p.N * p.H * p.W - 1) * p.ldx + (unsigned)p.Cin) * 4u), 0x00020000);
+  const auto rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.w), 0, (int)((unsigned)p.Kp * p.Np * 6u),
+                                                      0x00020000);
+  unsigned a_off[APASS];                                  // pointwise: (pixel * ldx + slot) * 4, fixed over K
   int a_slot[APASS];
   int a_pix[KXK ? APASS : 1], a_ih0[KXK ? APASS : 1], a_iw0[KXK ? APASS : 1];
 #pragma unroll
@@ -140,24 +163,22 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void gemm1x1s_kernel(const ConvArgs
       a_pix[ps] = n * p.H * p.W;
       a_ih0[ps] = oh * p.SH - p.PT;
       a_iw0[ps] = ow * p.SW - p.PL;
-      a_src[ps] = p.x;
+      a_off[ps] = 0;
     } else {
-      a_src[ps] = p.x + (size_t)m * p.ldx;
+      a_off[ps] = ((unsigned)m * p.ldx + a_slot[ps]) * 4u;
     }
   }
   const int chunks_per_tap = KXK ? p.Cin / BK : 1;
-  // packed split weight: 16-byte unit (kg, part, n) at ((kg * 3 + part) * Np + n) * 4 floats
-  const float* b_src[BPASS];
+  // packed split weight: 16-byte unit (kg, part, n) at ((kg * 3 + part) * Np + n) * 16 bytes
+  unsigned b_off[BPASS];
 #pragma unroll
   for (int q = 0; q < BPASS; ++q) {
     const int idx = tid + q * NT;
-    int r = idx / BN;
+    const int r = idx / BN;
     const int j = idx - r * BN;
-    r = r < 12 ? r : 11;
-    const int col = n0 + j < p.Np ? n0 + j : 0;
-    b_src[q] = p.w + ((size_t)r * p.Np + col) * 4;
+    b_off[q] = r < 12 && n0 + j < p.Np ? ((unsigned)r * p.Np + n0 + j) * 16u : OOB;
   }
-  const size_t b_step = (size_t)12 * p.Np * 4;           // floats per K-step in the packed weight
+  const int b_step = 12 * p.Np * 16;                      // bytes per K-step in the packed weight
 
   auto issue = [&](int kt, int stage) {
     float* sA = smem + stage * STAGE;
@@ -171,22 +192,19 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void gemm1x1s_kernel(const ConvArgs
     }
 #pragma unroll
     for (int ps = 0; ps < APASS; ++ps) {
-      const float* src;
-      if constexpr (KXK) {
+      if constexpr (KXK) {                                // padding taps: out-of-range offset -> zeros
         const int ih = a_ih0[ps] + kh, iw = a_iw0[ps] + kw;
         const bool ok = (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W && kt * BK < p.K;
-        src = ok ? p.x + (size_t)(a_pix[ps] + ih * p.W + iw) * p.ldx + c0 + a_slot[ps] : g_zero_page_s + a_slot[ps];
-      } else {
-        int k = kt * BK + a_slot[ps];
-        k = k < p.K ? k : 0;
-        src = a_src[ps] + k;
+        const unsigned off = ok ? ((unsigned)(a_pix[ps] + ih * p.W + iw) * p.ldx + c0 + a_slot[ps]) * 4u : OOB;
+        dma16(rs_x, sA + (ps * NT + wave_u * 64) * 4, off, 0);
+      } else {                                            // k >= K reads the next pixel (finite) or zeros: weights there are 0
+        dma16(rs_x, sA + (ps * NT + wave_u * 64) * 4, a_off[ps], kt * BK * 4);
       }
-      __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(sA + (ps * NT + wave * 64) * 4), 16, 0, 0);
     }
 #pragma unroll
     for (int q = 0; q < BPASS; ++q)
-      __builtin_amdgcn_global_load_lds((gptr_t)(b_src[q] + kt * b_step), (lptr_t)(sB + (q * NT + wave * 64) * 4),
-                                       16, 0, 0);
+      if ((q + 1) * NT <= BROWS || q * NT + wave_u * 64 < BROWS)     // whole waves: 12 * BN is a multiple of 64
+        dma16(rs_w, sB + (q * NT + wave_u * 64) * 4, b_off[q], kt * b_step);
   };
 
   f32x16 acc[TM][TN];
@@ -199,6 +217,9 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void gemm1x1s_kernel(const ConvArgs
 
   const int nk = p.Kp / BK;
   issue(0, 0);
+  if constexpr (NS == 3) {
+    if (nk > 1) issue(1, 1);
+  }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
 
@@ -218,8 +239,8 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void gemm1x1s_kernel(const ConvArgs
   const unsigned b_base = lds0 + (unsigned)(BM * BK * 4) + (unsigned)((lh * 3 * BN + wn * TN * 32 + li) * 16);
 
   EpiPrefetch<TM, TN> pre;
+  int cur = 0;
   for (int kt = 0; kt < nk; ++kt) {
-    const int cur = kt & 1;
     if (kt == nk - 1) pre.template issue<WM, WN>(p, m0, n0, M, epi_vec);
     const unsigned so = (unsigned)(cur * STAGE * 4);
     const unsigned bo = b_base + so;
@@ -239,7 +260,10 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void gemm1x1s_kernel(const ConvArgs
       rb[0][j][2] = lds_rd<0>(bo + (unsigned)(2 * BN * 16 + j * 512));
     }
     __builtin_amdgcn_sched_barrier(0);
-    if (kt + 1 < nk) issue(kt + 1, cur ^ 1);          // DMA of the next tile flies during this K-step
+    int nxt = cur + NS - 1;                           // stage that was read NS-1 ... 1 K-steps ago: free
+    nxt = nxt >= NS ? nxt - NS : nxt;
+    const bool more = kt + NS - 1 < nk;
+    if (more) issue(kt + NS - 1, nxt);                // DMA of K-step kt+NS-1 flies during this one (and the next)
     lgkm_wait();
     // chunk 1 operands in flight while chunk 0 is split and multiplied
 #pragma unroll
@@ -258,41 +282,52 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void gemm1x1s_kernel(const ConvArgs
       Frag3 fa[TM];
 #pragma unroll
       for (int i = 0; i < TM; ++i) fa[i] = split8<RELU>(ra[0][i][0], ra[0][i][1]);
+      bf16x8 fb[TN][3];
 #pragma unroll
-      for (int j = 0; j < TN; ++j) {
-        const bf16x8 fb[3] = {as_bf(rb[0][j][0]), as_bf(rb[0][j][1]), as_bf(rb[0][j][2])};
+      for (int j = 0; j < TN; ++j)
 #pragma unroll
-        for (int i = 0; i < TM; ++i) mfma6(fa[i], fb, acc[i][j]);
-      }
+        for (int q = 0; q < 3; ++q) fb[j][q] = as_bf(rb[0][j][q]);
+      mfma6_tiles<TM, TN>(fa, fb, acc);
     }
     lgkm_wait();
     {
       Frag3 fa[TM];
 #pragma unroll
       for (int i = 0; i < TM; ++i) fa[i] = split8<RELU>(ra[1][i][0], ra[1][i][1]);
+      bf16x8 fb[TN][3];
 #pragma unroll
-      for (int j = 0; j < TN; ++j) {
-        const bf16x8 fb[3] = {as_bf(rb[1][j][0]), as_bf(rb[1][j][1]), as_bf(rb[1][j][2])};
+      for (int j = 0; j < TN; ++j)
 #pragma unroll
-        for (int i = 0; i < TM; ++i) mfma6(fa[i], fb, acc[i][j]);
-      }
+        for (int q = 0; q < 3; ++q) fb[j][q] = as_bf(rb[1][j][q]);
+      mfma6_tiles<TM, TN>(fa, fb, acc);
     }
 
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // K-step kt+1 must have landed: with three stages the loads just issued (K-step kt+2) may stay in flight
+    // (in-order counter: "at most the loads of K-step kt+2 outstanding"; a wave that sat out the partial last B pass
+    // issued one load less)
+    if (NS == 3 && more) {
+      if (BPASS * NT <= BROWS || (BPASS - 1) * NT + wave_u * 64 < BROWS)
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(APASS + BPASS) : "memory");
+      else
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(APASS + BPASS - 1) : "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
     __syncthreads();
+    cur = cur + 1 == NS ? 0 : cur + 1;
   }
 
   conv_epilogue<WM, WN, TM, TN, UP2, true>(p, acc, smem, m0, n0, M, epi_vec, pre);
 }
 
-template <int WM, int WN, int TM, int TN, bool UP2, bool RELU, bool KXK = false>
+template <int WM, int WN, int TM, int TN, bool UP2, bool RELU, bool KXK = false, int NS = 2>
 int launch_variant(const ConvArgs& a, int epi, unsigned tiles, hipStream_t s) {
   constexpr int BM = WM * TM * 32, BN = WN * TN * 32, NT = WM * WN * 64;
   constexpr int BPASS = (12 * BN + NT - 1) / NT;
-  constexpr int kStage = 2 * (BM * BK + BPASS * NT * 4), kEpi = WM * WN * 32 * (TN * 32 + 4);
+  constexpr int kStage = NS * (BM * BK + 12 * BN * 4), kEpi = WM * WN * 32 * (TN * 32 + 4);
   constexpr size_t lds = (size_t)(kStage > kEpi ? kStage : kEpi) * sizeof(float);
   static_assert(lds <= 160 * 1024, "LDS budget");
-  auto kern = gemm1x1s_kernel<WM, WN, TM, TN, UP2, RELU, KXK>;
+  auto kern = gemm1x1s_kernel<WM, WN, TM, TN, UP2, RELU, KXK, NS>;
   if (lds > 64 * 1024) {
     static bool once = (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
                                             (int)lds), true);
@@ -302,7 +337,7 @@ int launch_variant(const ConvArgs& a, int epi, unsigned tiles, hipStream_t s) {
   return check_launch();
 }
 
-template <int WM, int WN, int TM, int TN>
+template <int WM, int WN, int TM, int TN, int NS = 2>
 int launch_cfg(const ConvArgs& a, int epi, hipStream_t s) {
   constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
   const long long M = (long long)a.N * a.OH * a.OW;
@@ -313,15 +348,15 @@ int launch_cfg(const ConvArgs& a, int epi, hipStream_t s) {
     if constexpr (TM * TN >= 6) {
       return DH_EUNSUPPORTED;
     } else {
-      return a.pre_relu ? launch_variant<WM, WN, TM, TN, true, true>(a, epi, t, s)
-                        : launch_variant<WM, WN, TM, TN, true, false>(a, epi, t, s);
+      return a.pre_relu ? launch_variant<WM, WN, TM, TN, true, true, false, NS>(a, epi, t, s)
+                        : launch_variant<WM, WN, TM, TN, true, false, false, NS>(a, epi, t, s);
     }
   }
   if (!(a.KH == 1 && a.KW == 1 && a.SH == 1 && a.SW == 1 && a.PT == 0 && a.PL == 0))
-    return a.pre_relu ? launch_variant<WM, WN, TM, TN, false, true, true>(a, epi, t, s)
-                      : launch_variant<WM, WN, TM, TN, false, false, true>(a, epi, t, s);
-  return a.pre_relu ? launch_variant<WM, WN, TM, TN, false, true>(a, epi, t, s)
-                    : launch_variant<WM, WN, TM, TN, false, false>(a, epi, t, s);
+    return a.pre_relu ? launch_variant<WM, WN, TM, TN, false, true, true, NS>(a, epi, t, s)
+                      : launch_variant<WM, WN, TM, TN, false, false, true, NS>(a, epi, t, s);
+  return a.pre_relu ? launch_variant<WM, WN, TM, TN, false, true, false, NS>(a, epi, t, s)
+                    : launch_variant<WM, WN, TM, TN, false, false, false, NS>(a, epi, t, s);
 }
 
 }  // namespace
@@ -330,6 +365,9 @@ bool gemm1x1_eligible(const ConvArgs& a);
 
 int launch_gemm1x1_split(const ConvArgs& a, int cfg, int epi, hipStream_t s) {
   if (!gemm1x1_eligible(a)) return DH_EUNSUPPORTED;
+  // 32-bit byte offsets into the buffer descriptors
+  if ((long long)a.N * a.H * a.W * a.ldx * 4 > 0xf0000000LL || (long long)a.Kp * a.Np * 6 > 0xf0000000LL)
+    return DH_EUNSUPPORTED;
   switch (cfg) {
     case 0: return launch_cfg<2, 2, 2, 3>(a, epi, s);
     case 1: return launch_cfg<2, 2, 2, 2>(a, epi, s);
@@ -340,8 +378,15 @@ int launch_gemm1x1_split(const ConvArgs& a, int cfg, int epi, hipStream_t s) {
     case 6: return launch_cfg<2, 1, 1, 2>(a, epi, s);
     case 7: return launch_cfg<2, 1, 1, 1>(a, epi, s);
     case 8: return launch_cfg<1, 1, 1, 1>(a, epi, s);
+    // one work-group per CU, three LDS stages: two K-steps of DMA in flight, bigger tiles = less L2 -> LDS traffic per MAC
+    case 9: return launch_cfg<8, 1, 1, 3, 3>(a, epi, s);      // 256 x 96, 8 waves
+    case 10: return launch_cfg<4, 1, 1, 3, 3>(a, epi, s);     // 128 x 96, 4 waves
+    case 11: return launch_cfg<8, 1, 1, 2, 3>(a, epi, s);     // 256 x 64
+    case 12: return launch_cfg<4, 2, 1, 3, 2>(a, epi, s);     // 128 x 192, 8 waves, two stages
   }
   return DH_EINVAL;
 }
+
+int gemm1x1_split_num_cfgs() { return 13; }
 
 }  // namespace dh

@@ -486,7 +486,7 @@ class BoundPlan:
             sig = (self.n, step.kind) + self._conv_signature(step) + ((('u8',) if cargs.x_u8 else ())) + \
                 ((('bf16x3',) if cargs.w_split else ()))
             if cargs.w_split:
-                ncfg = 9                                    # the split kernels exist in the 9 GEMM tile shapes only
+                ncfg = lib.dh_conv2d_num_split_tile_cfgs()
             if sig not in table:
                 best, best_ms = -1, float('inf')
                 for cfg in range(ncfg):

@@ -88,6 +88,7 @@ int dh_conv2d_pack_weights_split_host(const float* w_hwio_host, uint16_t* packed
                                       int Cout);
 /* tile_cfg < 0: library heuristic; 0..dh_conv2d_num_tile_cfgs()-1 forces a tiling (autotuning hook) */
 int dh_conv2d_num_tile_cfgs(void);
+int dh_conv2d_num_split_tile_cfgs(void); /* tilings of the w_split = 1 kernels: tile_cfg in [0, this) */
 int dh_conv2d_pick_tile_cfg(int M, int Cout);
 int dh_conv2d_f32(const dh_conv_args* a, int tile_cfg, void* stream);
 

@@ -465,7 +465,7 @@ def test_conv2d_split_bf16(case, hip_lib, cuda):
               up2=up2)
     f32 = F.conv2d(d(x), k, **kw)
     outs = {}
-    for cfg in range(-1, 9):
+    for cfg in range(-1, hip_lib.dh_conv2d_num_split_tile_cfgs()):
         try:
             outs[cfg] = F.conv2d(d(x), k, split=True, tile_cfg=cfg, **kw)
         except Exception as e:

@@ -31,14 +31,17 @@ for (h, cin, cout, ks, relu, res) in SH:
     a.KH = a.KW = ks; a.SH = a.SW = 1; a.PT = a.PL = (ks - 1) // 2
     a.K, a.Kp, a.Np, a.ldr1, a.pre_relu = ks * ks * cin, kp, np_, cout, int(relu)
     res_ = {}
-    for tag, wt, split, cfgs in (('f32', wf[0], 0, range(9, 18)), ('bf16x3', ws, 1, range(9))):
+    allc = {}
+    for tag, wt, split, cfgs in (('f32', wf[0], 0, range(9, 18)), ('bf16x3', ws, 1, range(lib.dh_conv2d_num_split_tile_cfgs()))):
         a.w, a.w_split = wt.data_ptr(), split
-        best = min((timed(lambda c=c: lib.dh_conv2d_f32(C.byref(a), c, st)), c) for c in cfgs
-                   if lib.dh_conv2d_f32(C.byref(a), c, st) == 0)
+        ts = {c: timed(lambda c=c: lib.dh_conv2d_f32(C.byref(a), c, st)) for c in cfgs
+              if lib.dh_conv2d_f32(C.byref(a), c, st) == 0}
+        allc[tag] = {str(c): round(v, 1) for c, v in ts.items()}
+        best = min((v, c) for c, v in ts.items())
         res_[tag] = best
     flop = 2.0 * n * h * h * ks * ks * cin * cout
     row = dict(shape=[n, h, h, cin, cout, ks], relu=relu, res=res, f32_us=res_['f32'][0], f32_cfg=res_['f32'][1],
                split_us=res_['bf16x3'][0], split_cfg=res_['bf16x3'][1], speedup=res_['f32'][0] / res_['bf16x3'][0],
-               f32_tflops=flop / res_['f32'][0] / 1e6, split_tflops_fp32_equiv=flop / res_['bf16x3'][0] / 1e6)
+               f32_tflops=flop / res_['f32'][0] / 1e6, split_tflops_fp32_equiv=flop / res_['bf16x3'][0] / 1e6, split_all=allc['bf16x3'])
     rows.append(row); print(json.dumps(row))
 json.dump(rows, open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'gpurun_out', 'bench_split.json'), 'w'), indent=1)
