@@ -3,7 +3,7 @@
 // 1x1 projections (reference deephar/layers.py:74-80, 258-301; models/reception.py:43-59,145-164).
 //
 // Same MFMA core and fragment mapping as conv_igemm.hip (v_mfma_f32_32x32x2_f32, exact fp32), but the
-// staging is LDS-DMA: global_load_lds_dwordx4 writes both operand tiles straight into LDS, double buffered,
+// staging is LDS-DMA: buffer_load_dwordx4 ... lds writes both operand tiles straight into LDS, double buffered,
 // so a K-step costs no staging VGPRs, no ds_write and ONE barrier; the DMA of tile k+1 is in flight
 // during the whole MFMA block of tile k.
 //   A (activations, rows = pixels): LDS image [BM][32] floats, 128-byte rows, 16-byte slots XOR-swizzled
@@ -19,11 +19,18 @@ namespace {
 
 constexpr int BK = 32;
 
-// Source of the DMA for rows / taps that fall into the zero padding of a K x K convolution (KXK variant).
-__device__ __attribute__((aligned(128))) float g_zero_page[BK] = {};
-
-typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
+constexpr unsigned OOB = 0xfffffff0u;   // a buffer offset beyond every descriptor used here: the load returns zeros
+
+// buffer_load_dwordx4 ... offen lds: 16 bytes per lane from (descriptor base + voff + soff) to LDS (wave-uniform `dst`
+// + lane * 16).  The builtin only exists for the gfx950 pass: hipcc's host pass silently drops a kernel TEMPLATE whose
+// body names it (no host stub is emitted), hence the guard.
+template <typename RSRC>
+__device__ __forceinline__ void dma16(RSRC rs, float* dst, unsigned voff, int soff) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lptr_t)dst, 16, voff, soff, 0, 0);
+#endif
+}
 
 // Fragment reads go through inline asm on purpose: with an LDS-DMA in flight hipcc cannot prove that the DMA's
 // LDS destination (the other stage) does not alias an ordinary ds_read and puts `s_waitcnt vmcnt(0)` in front
@@ -90,8 +97,15 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void gemm1x1_kernel(const ConvArgs 
   const int m0 = (tile / tiles_n) * BM;
   const int n0 = (tile % tiles_n) * BN;
 
-  // ---- per-thread DMA sources (fixed over K except for the k offset)
-  const float* a_src[APASS];
+  // ---- per-thread DMA sources: byte offsets into two buffer descriptors (activations, packed weight), fixed over K;
+  // the K-step offset is SCALAR (soffset of buffer_load ... lds), so a K-step costs no 64-bit address VALU -- on gfx950
+  // every VALU instruction beside an fp32 MFMA is paid in full (profiles/r02_sepconv_fusion_study.md section 3)
+  const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+  const auto rs_x = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(p.x), 0, (int)(((unsigned)(p.N * p.H * p.W - 1) * p.ldx + (unsigned)p.Cin) * 4u), 0x00020000);
+  const auto rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.w), 0, (int)((unsigned)p.Kp * p.Np * 4u),
+                                                      0x00020000);
+  unsigned a_off[APASS];                            // pointwise: (pixel * ldx + slot) * 4
   int a_slot[APASS];
   int a_pix[KXK ? APASS : 1], a_ih0[KXK ? APASS : 1], a_iw0[KXK ? APASS : 1];   // KXK: frame base pixel, top-left tap
 #pragma unroll
@@ -107,21 +121,21 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void gemm1x1_kernel(const ConvArgs 
       a_pix[ps] = n * p.H * p.W;
       a_ih0[ps] = oh * p.SH - p.PT;
       a_iw0[ps] = ow * p.SW - p.PL;
-      a_src[ps] = p.x;
+      a_off[ps] = 0;
     } else {
-      a_src[ps] = p.x + (size_t)m * p.ldx;
+      a_off[ps] = ((unsigned)m * p.ldx + a_slot[ps]) * 4u;
     }
   }
   const int chunks_per_tap = KXK ? p.Cin / BK : 1;
-  const float* b_src[BPASS];
+  unsigned b_off[BPASS];
 #pragma unroll
   for (int q = 0; q < BPASS; ++q) {
     const int idx = tid + q * NT;
     const int kq = idx / BN, j = idx - kq * BN;
     const int col = n0 + j < p.Np ? n0 + j : 0;
-    b_src[q] = p.w + ((size_t)kq * p.Np + col) * 4;
+    b_off[q] = ((unsigned)kq * p.Np + col) * 16u;
   }
-  const size_t b_step = (size_t)8 * p.Np * 4;       // floats per K-step in the packed weight
+  const int b_step = 8 * p.Np * 16;                 // bytes per K-step in the packed weight
 
   auto issue = [&](int kt, int stage) {
     float* sA = smem + stage * STAGE;
@@ -135,22 +149,17 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void gemm1x1_kernel(const ConvArgs 
     }
 #pragma unroll
     for (int ps = 0; ps < APASS; ++ps) {
-      const float* src;
-      if constexpr (KXK) {
+      if constexpr (KXK) {                          // padding taps: out-of-range offset -> the DMA writes zeros
         const int ih = a_ih0[ps] + kh, iw = a_iw0[ps] + kw;
         const bool ok = (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W && kt * BK < p.K;
-        src = ok ? p.x + (size_t)(a_pix[ps] + ih * p.W + iw) * p.ldx + c0 + a_slot[ps] : g_zero_page + a_slot[ps];
-      } else {
-        int k = kt * BK + a_slot[ps];
-        k = k < p.K ? k : 0;
-        src = a_src[ps] + k;
+        const unsigned off = ok ? ((unsigned)(a_pix[ps] + ih * p.W + iw) * p.ldx + c0 + a_slot[ps]) * 4u : OOB;
+        dma16(rs_x, sA + (ps * NT + wave_u * 64) * 4, off, 0);
+      } else {                                      // k >= K: the next pixel's (finite) data or zeros, times zero weights
+        dma16(rs_x, sA + (ps * NT + wave_u * 64) * 4, a_off[ps], kt * BK * 4);
       }
-      __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(sA + (ps * NT + wave * 64) * 4), 16, 0, 0);
     }
 #pragma unroll
-    for (int q = 0; q < BPASS; ++q)
-      __builtin_amdgcn_global_load_lds((gptr_t)(b_src[q] + kt * b_step), (lptr_t)(sB + (q * NT + wave * 64) * 4),
-                                       16, 0, 0);
+    for (int q = 0; q < BPASS; ++q) dma16(rs_w, sB + (q * NT + wave_u * 64) * 4, b_off[q], kt * b_step);
   };
 
   f32x16 acc[TM][TN];
@@ -294,7 +303,8 @@ bool gemm1x1_eligible(const ConvArgs& a) {
   // K x K: a K-step must not straddle filter taps, the up-sampling epilogue is only built for the pointwise form
   const bool kxk = a.Cin % BK == 0 && !a.up2 && a.KH >= 1 && a.KW >= 1 && a.SH >= 1 && a.SW >= 1 && a.PT >= 0 &&
                    a.PL >= 0;
-  return aligned && (pointwise || kxk);
+  const bool fits32 = (long long)a.N * a.H * a.W * a.ldx * 4 <= 0xf0000000LL;      // 32-bit buffer offsets
+  return aligned && fits32 && (pointwise || kxk);
 }
 
 int launch_gemm1x1(const ConvArgs& a, int cfg, int epi, hipStream_t s) {
