@@ -245,6 +245,42 @@ __global__ __launch_bounds__(WM* WN * 64, WM * WN >= 8 ? 2 : 2) void gemm1x1s_ke
     const unsigned so = (unsigned)(cur * STAGE * 4);
     const unsigned bo = b_base + so;
 
+    int nxt = cur + NS - 1;                           // stage that was read NS-1 ... 1 K-steps ago: free
+    nxt = nxt >= NS ? nxt - NS : nxt;
+    const bool more = kt + NS - 1 < nk;
+    if constexpr (TM * TN >= 6) {
+      // big per-wave tile (64 x 96): LDS fragment traffic per MFMA is what bounds this kernel (each wave re-reads its
+      // B columns: 0.61 KB per MFMA at 32 x 96, 0.36 KB at 64 x 96), and 96 accumulators leave room for ONE chunk of
+      // operands at a time -- no operand double buffering, the partner wave of the SIMD covers the read latency
+#pragma unroll
+      for (int c = 0; c < 2; ++c) {
+        float4 ra1[TM][2], rb1[TN][3];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+          ra1[i][0] = lds_rd<0>(a_base[i][c][0] + so);
+          ra1[i][1] = lds_rd<0>(a_base[i][c][1] + so);
+        }
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          rb1[j][0] = lds_rd<0>(bo + (unsigned)((6 * c) * BN * 16 + j * 512));
+          rb1[j][1] = lds_rd<0>(bo + (unsigned)((6 * c + 1) * BN * 16 + j * 512));
+          rb1[j][2] = lds_rd<0>(bo + (unsigned)((6 * c + 2) * BN * 16 + j * 512));
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (c == 0 && more) issue(kt + NS - 1, nxt);
+        lgkm_wait();
+        Frag3 fa[TM];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) fa[i] = split8<RELU>(ra1[i][0], ra1[i][1]);
+        bf16x8 fb[TN][3];
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+          for (int q = 0; q < 3; ++q) fb[j][q] = as_bf(rb1[j][q]);
+        mfma6_tiles<TM, TN>(fa, fb, acc);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    } else {
     float4 ra[2][TM][2];
     float4 rb[2][TN][3];
     // chunk 0 operands
@@ -260,9 +296,6 @@ __global__ __launch_bounds__(WM* WN * 64, WM * WN >= 8 ? 2 : 2) void gemm1x1s_ke
       rb[0][j][2] = lds_rd<0>(bo + (unsigned)(2 * BN * 16 + j * 512));
     }
     __builtin_amdgcn_sched_barrier(0);
-    int nxt = cur + NS - 1;                           // stage that was read NS-1 ... 1 K-steps ago: free
-    nxt = nxt >= NS ? nxt - NS : nxt;
-    const bool more = kt + NS - 1 < nk;
     if (more) issue(kt + NS - 1, nxt);                // DMA of K-step kt+NS-1 flies during this one (and the next)
     lgkm_wait();
     // chunk 1 operands in flight while chunk 0 is split and multiplied
@@ -278,28 +311,38 @@ __global__ __launch_bounds__(WM* WN * 64, WM * WN >= 8 ? 2 : 2) void gemm1x1s_ke
       rb[1][j][2] = lds_rd<0>(bo + (unsigned)(8 * BN * 16 + j * 512));
     }
     __builtin_amdgcn_sched_barrier(0);
-    {
-      Frag3 fa[TM];
+    // chunk 0 is split with nothing to hide behind; chunk 1 is split UNDER chunk 0's MFMAs: the scheduler is told to
+    // place VPM VALU instructions after every MFMA (about four hide under a v_mfma_f32_32x32x16_bf16, measured).
+    Frag3 fa0[TM], fa1[TM];
 #pragma unroll
-      for (int i = 0; i < TM; ++i) fa[i] = split8<RELU>(ra[0][i][0], ra[0][i][1]);
+    for (int i = 0; i < TM; ++i) fa0[i] = split8<RELU>(ra[0][i][0], ra[0][i][1]);
+    lgkm_wait();                                      // chunk 1 operands have landed
+    {
       bf16x8 fb[TN][3];
 #pragma unroll
       for (int j = 0; j < TN; ++j)
 #pragma unroll
         for (int q = 0; q < 3; ++q) fb[j][q] = as_bf(rb[0][j][q]);
-      mfma6_tiles<TM, TN>(fa, fb, acc);
-    }
-    lgkm_wait();
-    {
-      Frag3 fa[TM];
 #pragma unroll
-      for (int i = 0; i < TM; ++i) fa[i] = split8<RELU>(ra[1][i][0], ra[1][i][1]);
+      for (int i = 0; i < TM; ++i) fa1[i] = split8<RELU>(ra[1][i][0], ra[1][i][1]);
+      mfma6_tiles<TM, TN>(fa0, fb, acc);
+      constexpr int VPM = (52 + 6 * TN - 1) / (6 * TN);
+#pragma unroll
+      for (int u = 0; u < 6 * TM * TN; ++u) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);      // one MFMA
+        __builtin_amdgcn_sched_group_barrier(0x002, VPM, 0);    // VPM VALU
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    {
       bf16x8 fb[TN][3];
 #pragma unroll
       for (int j = 0; j < TN; ++j)
 #pragma unroll
         for (int q = 0; q < 3; ++q) fb[j][q] = as_bf(rb[1][j][q]);
-      mfma6_tiles<TM, TN>(fa, fb, acc);
+      mfma6_tiles<TM, TN>(fa1, fb, acc);
+    }
+
     }
 
     // K-step kt+1 must have landed: with three stages the loads just issued (K-step kt+2) may stay in flight
@@ -383,10 +426,11 @@ int launch_gemm1x1_split(const ConvArgs& a, int cfg, int epi, hipStream_t s) {
     case 10: return launch_cfg<4, 1, 1, 3, 3>(a, epi, s);     // 128 x 96, 4 waves
     case 11: return launch_cfg<8, 1, 1, 2, 3>(a, epi, s);     // 256 x 64
     case 12: return launch_cfg<4, 2, 1, 3, 2>(a, epi, s);     // 128 x 192, 8 waves, two stages
+    case 13: return launch_cfg<4, 2, 2, 3, 2>(a, epi, s);     // 256 x 192, 8 waves of 64 x 96
   }
   return DH_EINVAL;
 }
 
-int gemm1x1_split_num_cfgs() { return 13; }
+int gemm1x1_split_num_cfgs() { return 14; }
 
 }  // namespace dh
