@@ -72,10 +72,17 @@ struct EpiPrefetch {
   }
 };
 
+struct EpiNoHook {
+  __device__ __forceinline__ void operator()() const {}
+};
+
 // PRE: the caller issued EpiPrefetch::issue() (and the tiling holds a prefetched tile)
-template <int WM, int WN, int TM, int TN, bool UP2, bool PRE>
+// `staged` runs once the last row block's accumulators sit in the LDS slab (their registers are free from there on):
+// a kernel that finishes its tile in several column slices puts the next slice's residual prefetch there.
+template <int WM, int WN, int TM, int TN, bool UP2, bool PRE, typename HOOK = EpiNoHook>
 __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x16 (&acc)[TM][TN], float* smem, int m0,
-                                              int n0, int M, int epi_vec, const EpiPrefetch<TM, TN>& pre) {
+                                              int n0, int M, int epi_vec, const EpiPrefetch<TM, TN>& pre,
+                                              HOOK staged = HOOK()) {
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;
@@ -99,6 +106,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x16 (&acc)[T
       for (int r = 0; r < 16; ++r)
         sC[((r & 3) + 8 * (r >> 2) + 4 * lh) * LDC + j * 32 + li] = acc[i][j][r];
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                // wave-private slab: no barrier needed
+    if (i == TM - 1) staged();
     if (vec) {
       // pass 1: every load of this row block that is not in flight already
       float4 rr[kPre ? 1 : IT], sc[NSC], sh[NSC];
