@@ -47,6 +47,11 @@ PEAK_FP32_MFMA_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md "Peak F
 PEAK_HBM_GBS = 8000.0
 TILES = [(2, 2, 2, 3), (2, 2, 2, 2), (4, 1, 1, 3), (4, 1, 1, 2), (4, 1, 1, 1), (2, 1, 1, 3), (2, 1, 1, 2),
          (2, 1, 1, 1), (1, 1, 1, 1)]
+# split-bf16 tilings (csrc/gemm1x1s.hip launch_gemm1x1_split): cfg -> ((WM, WN, TM, TN), LDS stages); wide: cfg -> WM
+SPLIT_TILES = {i: (t, 2) for i, t in enumerate(TILES)}
+SPLIT_TILES.update({9: ((8, 1, 1, 3), 3), 10: ((4, 1, 1, 3), 3), 11: ((8, 1, 1, 2), 3), 12: ((4, 2, 1, 3), 2),
+                    13: ((4, 2, 2, 3), 2)})
+SPLIT_WIDE = {14: 4, 15: 2}
 
 
 # ---- models ------------------------------------------------------------------------------------------------------
@@ -149,12 +154,15 @@ def kernel_name(s):
         return 'sepconv_fused_kernel (tiling %d)' % cfg
     if cfg < 0:
         return 'conv (library-picked tiling)'
-    t = TILES[cfg % 9]
     b = lambda v: 'true' if v else 'false'
     a = s.attrs
     if a.get('w_split'):
         kxk = not (a['kh'] == a['kw'] == 1 and a['sh'] == a['sw'] == 1 and a['pt'] == a['pl'] == 0)
-        return 'gemm1x1s_kernel<%d, %d, %d, %d, %s, %s, %s>' % (t + (b(a['up2']), b(a['pre_relu']), b(kxk)))
+        if cfg in SPLIT_WIDE:
+            return 'gemm1x1s_wide_kernel<%d, %s, %s, %s>' % (SPLIT_WIDE[cfg], b(a['up2']), b(a['pre_relu']), b(kxk))
+        t, ns = SPLIT_TILES[cfg]
+        return 'gemm1x1s_kernel<%d, %d, %d, %d, %s, %s, %s, %d>' % (t + (b(a['up2']), b(a['pre_relu']), b(kxk), ns))
+    t = TILES[cfg % 9]
     if cfg >= 9:
         kxk = not (a['kh'] == a['kw'] == 1 and a['sh'] == a['sw'] == 1 and a['pt'] == a['pl'] == 0)
         return 'gemm1x1_kernel<%d, %d, %d, %d, %s, %s, %s>' % (t + (b(a['up2']), b(a['pre_relu']), b(kxk)))
