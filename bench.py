@@ -475,6 +475,10 @@ def main():
         sroof['peak_note'] = 'dense bf16 MFMA peak (2.5 PFLOP/s) / 6 partial products, in fp32-equivalent TFLOP/s'
         for key in ('frac',):
             sroof[key] = round(sroof['achieved'] / sroof['peak'], 4)
+        # v_mfma_f32_32x32x16_bf16 only sustains the nominal rate on constant operands: a bare MFMA stream on random bf16
+        # values runs at 1.89 PFLOP/s here (power-limited clock; tools/micro/mfma_data_power.hip,
+        # profiles/r02_mfma_data_power.txt).  `frac` stays priced against the nominal peak.
+        sroof['frac_of_sustained_on_random_operands'] = round(sroof['achieved'] / (1890.0 / 6.0), 4)
         sroof['all_mfma_conv_kernels']['frac_of_fp32_mfma_peak'] = sroof['all_mfma_conv_kernels'].pop('frac')
         sroof['whole_forward_frac_of_fp32_mfma_peak'] = sroof.pop('whole_forward_frac')
         split_leg = {'value': round(sframes * args.steps / sdt, 1), 'unit': 'frames/s',
