@@ -277,9 +277,11 @@ bool gemm1x1_eligible(const ConvArgs& a);
 int launch_gemm1x1(const ConvArgs& a, int cfg, int epi, hipStream_t s);
 int launch_gemm1x1_split(const ConvArgs& a, int cfg, int epi, hipStream_t s);
 int gemm1x1_split_num_cfgs();
+int gemm1x1_num_cfgs();
 
-// cfg 0..8: general implicit-GEMM kernel; cfg 9..17: the same tile shapes on the LDS-DMA pointwise kernel
-int conv_igemm_num_cfgs() { return 2 * kNumCfgs; }
+// cfg 0..8: general implicit-GEMM kernel; cfg 9..17: the same tile shapes on the LDS-DMA pointwise kernel; 18, 19: its
+// wide (32 x 192 per wave) tilings
+int conv_igemm_num_cfgs() { return kNumCfgs + gemm1x1_num_cfgs(); }
 
 // Default tiling when the caller does not autotune (measured on MI355X, tools/bench_ops.py): four waves
 // side by side along M with narrow per-wave tiles (more resident waves per SIMD) beat the 2x2-wave layouts;
@@ -306,7 +308,7 @@ int launch_conv_igemm(const ConvArgs& a, int cfg, hipStream_t s) {
   if (a.x_u8 && a.in_lut == nullptr) return DH_EINVAL;
   if (cfg < 0)
     cfg = conv_igemm_pick_cfg(a.N * a.OH * a.OW, a.Cout) + (!a.w_split && !a.x_u8 && gemm1x1_eligible(a) ? kNumCfgs : 0);
-  if (!a.w_split && cfg >= 2 * kNumCfgs) return DH_EINVAL;
+  if (!a.w_split && cfg >= kNumCfgs + gemm1x1_num_cfgs()) return DH_EINVAL;
   if (a.x_u8 && cfg >= kNumCfgs) return DH_EUNSUPPORTED;
   auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
   const int epi = (a.Cout % 4 == 0) && (a.ldy % 4 == 0) && al16(a.y) &&

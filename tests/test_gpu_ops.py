@@ -65,12 +65,13 @@ def test_conv2d_plain(case, hip_lib, cuda):
     assert e_hip <= 4 * e_cpu + 1e-6, (e_hip, e_cpu)
 
 
-@pytest.mark.parametrize('cfg', range(18))
+@pytest.mark.parametrize('cfg', range(20))
 def test_conv2d_every_tile_config(cfg, hip_lib, cuda):
-    """cfg 0..8: general implicit-GEMM kernel (3x3 here); cfg 9..17: the LDS-DMA pointwise kernel (1x1).
+    """cfg 0..8: general implicit-GEMM kernel (3x3 here); cfg 9..19: the LDS-DMA pointwise kernel (1x1; 18, 19 = its wide
+    32 x 192 per-wave tilings).
     All tilings must agree bit-for-bit (same K summation order), which is what lets the autotuner pick freely."""
     from deephar_amd import functional as F
-    assert hip_lib.dh_conv2d_num_tile_cfgs() == 18
+    assert hip_lib.dh_conv2d_num_tile_cfgs() == 20
     rng = np.random.default_rng(cfg % 9)
     ks = 3 if cfg < 9 else 1
     x = _rand(rng, (2, 19, 23, 96))           # M = 874: ragged in every BM
@@ -437,6 +438,38 @@ SPLIT_CASES = [
     (1, 32, 32, 64, 96, 3, 2, False, False, False),      # strided
     (2, 19, 23, 96, 200, 1, 1, True, True, False),       # ragged everywhere
 ]
+
+
+@pytest.mark.parametrize('case', SPLIT_CASES)
+def test_conv2d_dma_gemm_tilings_bitwise(case, hip_lib, cuda):
+    """The fp32 LDS-DMA GEMM family (cfg 9..19, incl. the wide 32 x 192 tilings with their 16-k K-steps and two-slice
+    epilogue) on the same shapes: pointwise, K x K, strided, fused up-sampling, ragged tails -- all bit-identical."""
+    from deephar_amd import functional as F
+    n, h, w, cin, cout, ks, st, relu, res, up2 = case
+    rng = np.random.default_rng(sum(int(v) for v in case) + 1)
+    x = _rand(rng, (n, h, w, cin))
+    k = _rand(rng, (ks, ks, cin, cout), np.sqrt(1.0 / (ks * ks * cin)))
+    sc = rng.uniform(0.5, 1.5, cout).astype(np.float32)
+    sh = _rand(rng, (cout,), 0.1)
+    oh, ow = -(-h // st), -(-w // st)
+    r1 = _rand(rng, (n, oh, ow, cout)) if res else None
+    r2 = _rand(rng, (n, 2 * oh, 2 * ow, cout)) if up2 else None
+    d = lambda a: None if a is None else torch.from_numpy(a).to(cuda)
+    kw = dict(strides=(st, st), padding='same', pre_relu=relu, post_scale=d(sc), post_shift=d(sh), res1=d(r1), res2=d(r2),
+              up2=up2)
+    outs = {}
+    for cfg in range(9, hip_lib.dh_conv2d_num_tile_cfgs()):
+        try:
+            outs[cfg] = F.conv2d(d(x), k, tile_cfg=cfg, **kw)
+        except Exception as e:
+            assert 'rc=-2' in str(e), e
+    torch.cuda.synchronize()
+    assert 18 in outs and 19 in outs and len(outs) >= 4
+    first = next(iter(outs.values()))
+    for cfg, y in outs.items():
+        assert torch.equal(y, first), 'DMA GEMM tiling %d differs' % cfg
+    general = F.conv2d(d(x), k, tile_cfg=4, **kw)                  # conv_igemm_kernel, same K order
+    assert torch.equal(general, first)
 
 
 @pytest.mark.parametrize('case', SPLIT_CASES)

@@ -44,7 +44,7 @@ def main():
         (256, 3, 32, 3, 2, 0, 0, 'stem 3x3 s2 3->32'),
         (64, 64, 96, 3, 1, 0, 0, 'stem 3x3 64->96 @64'),
     ]
-    cfgs = [-1] + (list(range(18)) if '--cfgs' in sys.argv else [])
+    cfgs = [-1] + (list(range(20)) if '--cfgs' in sys.argv else [])
     for (H, cin, cout, k, s, nres, up2, name) in shapes:
         x = torch.from_numpy(rng.standard_normal((N, H, H, cin)).astype(np.float32)).to(dev)
         w = (rng.standard_normal((k, k, cin, cout)) * 0.05).astype(np.float32)

@@ -32,7 +32,7 @@ for (h, cin, cout, ks, relu, res) in SH:
     a.K, a.Kp, a.Np, a.ldr1, a.pre_relu = ks * ks * cin, kp, np_, cout, int(relu)
     res_ = {}
     allc = {}
-    for tag, wt, split, cfgs in (('f32', wf[0], 0, range(9, 18)), ('bf16x3', ws, 1, range(lib.dh_conv2d_num_split_tile_cfgs()))):
+    for tag, wt, split, cfgs in (('f32', wf[0], 0, range(9, lib.dh_conv2d_num_tile_cfgs())), ('bf16x3', ws, 1, range(lib.dh_conv2d_num_split_tile_cfgs()))):
         a.w, a.w_split = wt.data_ptr(), split
         ts = {c: timed(lambda c=c: lib.dh_conv2d_f32(C.byref(a), c, st)) for c in cfgs
               if lib.dh_conv2d_f32(C.byref(a), c, st) == 0}
