@@ -152,6 +152,8 @@ def kernel_name(s):
     cfg = s.attrs.get('tile_cfg', -1)
     if s.kind == 'sepconv':
         return 'sepconv_fused_kernel (tiling %d)' % cfg
+    if s.attrs.get('split_k'):
+        return 'conv_splitk_kernel'
     if cfg < 0:
         return 'conv (library-picked tiling)'
     b = lambda v: 'true' if v else 'false'

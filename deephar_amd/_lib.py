@@ -59,6 +59,7 @@ SIGNATURES = {
     'dh_conv2d_num_tile_cfgs': (C.c_int, []),
     'dh_conv2d_num_split_tile_cfgs': (C.c_int, []),
     'dh_conv2d_pick_tile_cfg': (C.c_int, [C.c_int, C.c_int]),
+    'dh_conv2d_uses_split_k': (C.c_int, [C.POINTER(ConvArgs)]),
     'dh_conv2d_f32': (C.c_int, [C.POINTER(ConvArgs), C.c_int, vp]),
     'dh_sepconv2d_num_tile_cfgs': (C.c_int, []),
     'dh_sepconv2d_f32': (C.c_int, [C.POINTER(SepConvArgs), C.c_int, vp]),

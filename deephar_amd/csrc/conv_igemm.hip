@@ -278,6 +278,8 @@ int launch_gemm1x1(const ConvArgs& a, int cfg, int epi, hipStream_t s);
 int launch_gemm1x1_split(const ConvArgs& a, int cfg, int epi, hipStream_t s);
 int gemm1x1_split_num_cfgs();
 int gemm1x1_num_cfgs();
+bool conv_is_skinny(const ConvArgs& a);
+int launch_conv_splitk(const ConvArgs& a, hipStream_t s);
 
 // cfg 0..8: general implicit-GEMM kernel; cfg 9..17: the same tile shapes on the LDS-DMA pointwise kernel; 18, 19: its
 // wide (32 x 192 per wave) tilings
@@ -306,6 +308,9 @@ int launch_conv_igemm(const ConvArgs& a, int cfg, hipStream_t s) {
   if ((long long)a.N * a.H * a.W > 0x7fffffffLL || (long long)a.N * a.OH * a.OW * (a.up2 ? 4 : 1) > 0x7fffffffLL)
     return DH_EINVAL;
   if (a.x_u8 && a.in_lut == nullptr) return DH_EINVAL;
+  // tiny output, long reduction: the in-work-group split-K kernel, whatever tiling was asked for (shape rule: the
+  // result bits of a layer must not depend on a timing-based choice)
+  if (conv_is_skinny(a)) return cfg < kNumCfgs + gemm1x1_num_cfgs() ? launch_conv_splitk(a, s) : DH_EINVAL;
   if (cfg < 0)
     cfg = conv_igemm_pick_cfg(a.N * a.OH * a.OW, a.Cout) + (!a.w_split && !a.x_u8 && gemm1x1_eligible(a) ? kNumCfgs : 0);
   if (!a.w_split && cfg >= kNumCfgs + gemm1x1_num_cfgs()) return DH_EINVAL;

@@ -331,6 +331,92 @@ __global__ __launch_bounds__(64) void kronecker_kernel(const float* __restrict__
   }
 }
 
+// The same product for the shapes the models have (C % 4 == 0, 16-byte aligned rows): a [J x P] x [P x C] GEMM per
+// frame with J = 16 ... 20 -- bound by reading x once.  Work-group = (frame, 64-channel slab), 256 threads = 16 channel
+// quads x 16 pixel groups; a thread walks pixels g, g + 16, ... with float4 loads of its four channels (four pixels in
+// flight) and JT x 4 accumulators, the heat-map values of a pixel are the same address for the 16 lanes that share it;
+// the 16 pixel groups are then summed through LDS in two halves of JT / 2 joints (<= 40 KB: four work-groups per CU).
+// 64 x 1024 x 16 x 576 (the Penn merge model, batch of 4 clips): 1 079 us with the kernel above, see DESIGN.md for this one.
+template <int JT>
+__global__ __launch_bounds__(256) void kronecker_tiled_kernel(const float* __restrict__ hm, int ldh,
+                                                             const float* __restrict__ x, int ldx,
+                                                             float* __restrict__ f, int ldf, int P, int J, int C,
+                                                             int fvec) {
+  constexpr int HP = JT + 4;                                       // LDS pitch of a pixel's heat-map values (floats)
+  constexpr int JH = JT / 2;
+  extern __shared__ __attribute__((aligned(16))) float4 kr_red[];  // [16 groups][JT / 2][16 quads], then the h chunk
+  float* hs = reinterpret_cast<float*>(kr_red + 16 * JH * 16);     // [64 pixels][HP]
+  const int tid = threadIdx.x;
+  const int q = tid & 15, g = tid >> 4;
+  const int b = blockIdx.y;
+  const int c0 = blockIdx.x * 64 + q * 4;
+  const int cc = c0 < C ? c0 : C - 4;
+  const float* xb = x + (size_t)b * P * ldx + cc;
+  const float* hb = hm + (size_t)b * P * ldh;
+  const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int j0 = 0; j0 < J; j0 += JT) {
+    const int jn = min(JT, J - j0);
+    float4 acc[JT];
+#pragma unroll
+    for (int j = 0; j < JT; ++j) acc[j] = zero;
+    // chunks of 64 pixels = four per pixel group: their x rows are requested first, the chunk's heat-map values go
+    // through LDS meanwhile (coalesced load, zero-filled beyond jn / P), each thread then reads its pixels' JT values
+    // as float4 -- the same address for the 16 lanes of a group
+    for (int p0 = 0; p0 < P; p0 += 64) {
+      float4 xv[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int p = p0 + g + 16 * u;
+        xv[u] = *reinterpret_cast<const float4*>(xb + (size_t)(p < P ? p : P - 1) * ldx);
+      }
+      __syncthreads();                                             // previous chunk's readers are done
+      for (int i = tid; i < 64 * JT; i += 256) {
+        const int pp = i / JT, jj = i - pp * JT;
+        hs[pp * HP + jj] = (p0 + pp < P && jj < jn) ? hb[(size_t)(p0 + pp) * ldh + j0 + jj] : 0.f;
+      }
+      __syncthreads();
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const float4* hrow = reinterpret_cast<const float4*>(hs + (g + 16 * u) * HP);
+#pragma unroll
+        for (int j4 = 0; j4 < JT / 4; ++j4) {
+          const float4 h = hrow[j4];
+          const float hv[4] = {h.x, h.y, h.z, h.w};
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            float4& a = acc[j4 * 4 + e];
+            a.x = fmaf(hv[e], xv[u].x, a.x); a.y = fmaf(hv[e], xv[u].y, a.y);
+            a.z = fmaf(hv[e], xv[u].z, a.z); a.w = fmaf(hv[e], xv[u].w, a.w);
+          }
+        }
+      }
+    }
+    // sum over the 16 pixel groups, JT / 2 joints at a time
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+      __syncthreads();
+#pragma unroll
+      for (int j = 0; j < JH; ++j) kr_red[(g * JH + j) * 16 + q] = acc[half * JH + j];
+      __syncthreads();
+      for (int o = tid; o < JH * 16; o += 256) {                     // o = (joint of the half, channel quad)
+        const int j = o >> 4, qq = o & 15;
+        float4 t = kr_red[o];
+#pragma unroll
+        for (int gg = 1; gg < 16; ++gg) {
+          const float4 u = kr_red[(gg * JH + j) * 16 + qq];
+          t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w;
+        }
+        const int jj = j0 + half * JH + j, co = blockIdx.x * 64 + qq * 4;
+        if (half * JH + j < jn && co < C) {
+          float* dst = f + ((size_t)b * J + jj) * ldf + co;       // the result often lands in a packed row (odd pitch)
+          if (fvec) *reinterpret_cast<float4*>(dst) = t;
+          else { dst[0] = t.x; dst[1] = t.y; dst[2] = t.z; dst[3] = t.w; }
+        }
+      }
+    }
+  }
+}
+
 // y[b, c] = softmax_c( max_p x[b,p,c] + min_p x[b,p,c] ); one workgroup per b, C <= 1024
 __global__ __launch_bounds__(256) void global_maxmin_softmax_kernel(const float* __restrict__ x, int ldx,
                                                                     float* __restrict__ y, int P, int C,
@@ -435,6 +521,16 @@ int launch_depth_from_maps(const float* d, int ldd, const float* h, int ldh, flo
 int launch_kronecker(const float* hm, int ldh, const float* x, int ldx, float* f, int ldf, int B, int P, int J,
                      int C, hipStream_t s) {
   if (B <= 0 || P <= 0 || J <= 0 || C <= 0 || B > 65535) return DH_EINVAL;
+  auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
+  if (C % 4 == 0 && ldx % 4 == 0 && al16(x)) {
+    const dim3 grid((C + 63) / 64, B);
+    const int fvec = ldf % 4 == 0 && al16(f);
+    if (J <= 16 || (J > 20 && J % 20 != 0 && J % 16 == 0))
+      hipLaunchKernelGGL(kronecker_tiled_kernel<16>, grid, dim3(256), 16 * 8 * 16 * 16 + 64 * 20 * 4, s, hm, ldh, x, ldx, f, ldf, P, J, C, fvec);
+    else
+      hipLaunchKernelGGL(kronecker_tiled_kernel<20>, grid, dim3(256), 16 * 10 * 16 * 16 + 64 * 24 * 4, s, hm, ldh, x, ldx, f, ldf, P, J, C, fvec);
+    return check_launch();
+  }
   hipLaunchKernelGGL(kronecker_kernel, dim3((C + 63) / 64, B), dim3(64), 0, s, hm, ldh, x, ldx, f, ldf, P, J, C);
   return check_launch();
 }

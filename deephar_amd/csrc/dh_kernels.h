@@ -17,6 +17,7 @@ int launch_conv_igemm(const ConvArgs& a, int cfg, hipStream_t s);
 int launch_normalize_u8(const unsigned char* x, const float* lut, float* y, long long n_pixels, int C, hipStream_t s);
 int conv_igemm_pick_cfg(int M, int Cout);
 int conv_igemm_num_cfgs();
+bool conv_is_skinny(const ConvArgs& a);
 int gemm1x1_split_num_cfgs();
 int launch_dwconv(const DwArgs& a, hipStream_t s);
 int sepconv_num_cfgs();

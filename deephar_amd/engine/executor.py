@@ -190,6 +190,10 @@ class BoundPlan:
             return False
         y = s.outs['y']
         up = 2 if a['up2'] else 1
+        # tiny per-frame output + long reduction: the split-K kernel (fp32 weights; conv_splitk.hip conv_is_skinny)
+        if (y.shape[-3] // up) * (y.shape[-2] // up) <= 256 and a['kh'] * a['kw'] * a['Cin'] >= 768 and y.C <= 256 and \
+                a['Cin'] % 4 == 0:
+            return False
         same = x.shape[-3] == y.shape[-3] // up and x.shape[-2] == y.shape[-2] // up
         pointwise = a['kh'] == a['kw'] == 1 and a['sh'] == a['sw'] == 1 and a['pt'] == a['pl'] == 0 and same and \
             a['Cin'] % 4 == 0
@@ -487,6 +491,11 @@ class BoundPlan:
                 ((('bf16x3',) if cargs.w_split else ()))
             if cargs.w_split:
                 ncfg = lib.dh_conv2d_num_split_tile_cfgs()
+            if step.kind == 'conv' and lib.dh_conv2d_uses_split_k(args[0]):
+                step.attrs['tile_cfg'] = -1                      # shape rule: split-K kernel, no tilings to choose from
+                step.attrs['split_k'] = True
+                self.calls[i] = (fn, (args[0], -1), step)
+                continue
             if sig not in table:
                 best, best_ms = -1, float('inf')
                 for cfg in range(ncfg):

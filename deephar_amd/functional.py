@@ -246,15 +246,17 @@ def softargmax1d(hz):
     return z, vz
 
 
-def kronecker(hm, x):
+def kronecker(hm, x, out_pitch=None):
+    """layers.kronecker_prod.  `out_pitch` > C writes the rows into a wider (packed) buffer, as a plan does."""
     torch = _t()
     _chk(hm, x)
     b, hh, ww, j = hm.shape
     c = x.shape[-1]
-    f = torch.empty((b, j, c), device=hm.device)
-    _lib.check(_lib.load().dh_kronecker_f32(_p(hm), j, _p(x), c, _p(f), c, b, hh * ww, j, c, _stream()),
+    ld = c if out_pitch is None else int(out_pitch)
+    f = torch.zeros((b, j, ld), device=hm.device)
+    _lib.check(_lib.load().dh_kronecker_f32(_p(hm), j, _p(x), c, _p(f), ld, b, hh * ww, j, c, _stream()),
                'dh_kronecker_f32')
-    return f
+    return f if ld == c else f[..., :c]
 
 
 def global_maxmin_softmax(x, softmax=True):

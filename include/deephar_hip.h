@@ -90,6 +90,11 @@ int dh_conv2d_pack_weights_split_host(const float* w_hwio_host, uint16_t* packed
 int dh_conv2d_num_tile_cfgs(void);
 int dh_conv2d_num_split_tile_cfgs(void); /* tilings of the w_split = 1 kernels: tile_cfg in [0, this) */
 int dh_conv2d_pick_tile_cfg(int M, int Cout);
+/* 1 when dh_conv2d_f32 runs this convolution on the in-work-group split-K kernel (tiny per-frame output, long
+ * reduction: the action heads, deephar/models/blocks.py action_top / build_act_pred_block): a rule on OH*OW, K, Cout and
+ * Cin only, so that a layer's result bits never depend on tiling choice, batch size or alignment.  Such a layer takes
+ * fp32-packed weights (w_split = 0) and ignores tile_cfg. */
+int dh_conv2d_uses_split_k(const dh_conv_args* a);
 int dh_conv2d_f32(const dh_conv_args* a, int tile_cfg, void* stream);
 
 /* Stand-alone version of the same normalisation for inputs that do not feed a convolution directly:

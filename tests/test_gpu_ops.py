@@ -278,6 +278,25 @@ def test_kronecker_and_action_top(hip_lib, cuda):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize('b,h,w,j,c', [(3, 32, 32, 17, 288), (2, 16, 16, 20, 384), (2, 8, 8, 25, 60), (2, 5, 3, 16, 64),
+                                       (2, 9, 7, 41, 132), (2, 8, 8, 16, 30)])
+def test_kronecker_shapes(b, h, w, j, c, hip_lib, cuda):
+    """layers.kronecker_prod (layers.py:478-508) on the tiled kernel: joints that are no multiple of 4 (NTU: 17 + ...),
+    more joints than one pass holds, channel slabs with a tail, fewer pixels than pixel groups; C % 4 != 0 takes the
+    one-channel-per-thread kernel."""
+    from deephar_amd import functional as F
+    rng = np.random.default_rng(b + h + w + j + c)
+    hm = rng.random((b, h, w, j)).astype(np.float32)
+    hm /= hm.sum(axis=(1, 2), keepdims=True)
+    x = _rand(rng, (b, h, w, c))
+    ref = O.kronecker_prod(torch.from_numpy(hm).double(), torch.from_numpy(x).double())
+    got = F.kronecker(torch.from_numpy(hm).to(cuda), torch.from_numpy(x).to(cuda))
+    _close(got.cpu().double(), ref, atol=2e-6, rtol=1e-5, what='kron %s' % ((b, h, w, j, c),))
+    packed = F.kronecker(torch.from_numpy(hm).to(cuda), torch.from_numpy(x).to(cuda), out_pitch=c + 3)   # odd pitch
+    assert torch.equal(packed.contiguous(), got)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize('k,s,cout,power', [(3, 2, 32, 1), (7, 2, 64, 1), (3, 1, 16, (1, 2, 0.5))])
 def test_conv2d_uint8_frames_normalised_on_load(k, s, cout, power, hip_lib, cuda):
     """dh_conv_args.x_u8: the first convolution reads raw uint8 frames and applies the loader's normalisation
@@ -438,6 +457,78 @@ SPLIT_CASES = [
     (1, 32, 32, 64, 96, 3, 2, False, False, False),      # strided
     (2, 19, 23, 96, 200, 1, 1, True, True, False),       # ragged everywhere
 ]
+
+
+SKINNY_CASES = [
+    # n, h, w, cin, cout, k, stride, bn prologue, relu, residual
+    (4, 16, 16, 256, 256, 3, 1, False, True, False),     # merge action head: 3x3 over [T x J], K = 2304
+    (4, 16, 16, 112, 15, 3, 1, True, True, False),       # K = 1008, Cout = 15 (ragged tile), BN + ReLU prologue
+    (3, 32, 20, 192, 192, 3, 2, False, True, True),      # strided (out 16 x 10), residual
+    (2, 4, 4, 256, 15, 3, 1, False, False, False),       # 16 output pixels per clip: half-empty row tile
+    (5, 8, 8, 1024, 60, 1, 1, False, True, False),       # pointwise with a long K
+]
+
+
+@pytest.mark.parametrize('case', SKINNY_CASES)
+def test_conv2d_split_k_kernel(case, hip_lib, cuda):
+    """Tiny per-frame output + long reduction -> conv_splitk.hip, chosen by a rule on the layer's geometry: against the
+    fp64 truth, identical for every tile_cfg, batch-size invariant, identical through an unaligned input view."""
+    import ctypes as C
+    from deephar_amd import functional as F, _lib
+    n, h, w, cin, cout, ks, st, bn, relu, res = case
+    rng = np.random.default_rng(sum(int(v) for v in case))
+    x = _rand(rng, (n, h, w, cin))
+    k = _rand(rng, (ks, ks, cin, cout), np.sqrt(1.0 / (ks * ks * cin)))
+    ps = rng.uniform(0.5, 1.5, cin).astype(np.float32) if bn else None
+    pb = _rand(rng, (cin,), 0.1) if bn else None
+    sc = rng.uniform(0.5, 1.5, cout).astype(np.float32)
+    sh = _rand(rng, (cout,), 0.1)
+    oh, ow = -(-h // st), -(-w // st)
+    r1 = _rand(rng, (n, oh, ow, cout)) if res else None
+    t = lambda a: torch.from_numpy(a).double()
+    xin = t(x) * t(ps) + t(pb) if bn else t(x)
+    xin = O.relu(xin) if relu else xin
+    ref = O.conv2d(xin, t(k), (st, st), 'same') * t(sc) + t(sh)
+    if res:
+        ref = ref + t(r1)
+    xin32 = torch.from_numpy(x) * torch.from_numpy(ps) + torch.from_numpy(pb) if bn else torch.from_numpy(x)
+    xin32 = O.relu(xin32) if relu else xin32
+    cpu32 = O.conv2d(xin32, torch.from_numpy(k), (st, st), 'same') * torch.from_numpy(sc) + torch.from_numpy(sh)
+    if res:
+        cpu32 = cpu32 + torch.from_numpy(r1)
+    d = lambda a: None if a is None else torch.from_numpy(a).to(cuda)
+    kw = dict(strides=(st, st), padding='same', pre_scale=d(ps), pre_shift=d(pb), pre_relu=relu, post_scale=d(sc),
+              post_shift=d(sh))
+    got = F.conv2d(d(x), k, res1=d(r1), **kw)
+    torch.cuda.synchronize()
+    e_hip = (got.cpu().double() - ref).abs().max().item()
+    e_cpu = (cpu32.double() - ref).abs().max().item()
+    assert e_hip <= 4 * e_cpu + 1e-6, (e_hip, e_cpu)
+    for cfg in (0, 8, 12, hip_lib.dh_conv2d_num_tile_cfgs() - 1):           # the rule overrides the tiling
+        assert torch.equal(F.conv2d(d(x), k, res1=d(r1), tile_cfg=cfg, **kw), got)
+    half = F.conv2d(d(x[:2]), k, res1=d(None if r1 is None else r1[:2]), **kw)      # batch-size invariant
+    assert torch.equal(half, got[:2])
+    # the rule itself, and an input view that is not 16-byte aligned (pitch cin + 1, offset 1): same bits
+    a = _lib.ConvArgs()
+    wt, kp, np_ = F.pack_conv_weight(k, cuda)
+    wide = torch.zeros(n, h, w, cin + 1, device=cuda)
+    wide[..., 1:] = d(x)
+    y = torch.empty_like(got)
+    keep = [d(ps), d(pb), d(sc), d(sh), d(r1)]
+    a.x, a.w, a.y = wide.data_ptr() + 4, wt.data_ptr(), y.data_ptr()
+    a.pre_scale, a.pre_shift = (keep[0].data_ptr(), keep[1].data_ptr()) if bn else (None, None)
+    a.post_scale, a.post_shift = keep[2].data_ptr(), keep[3].data_ptr()
+    a.res1 = keep[4].data_ptr() if res else None
+    a.N, a.H, a.W, a.Cin, a.ldx, a.OH, a.OW, a.Cout, a.ldy = n, h, w, cin, cin + 1, oh, ow, cout, cout
+    a.KH = a.KW = ks; a.SH = a.SW = st
+    a.PT = max((oh - 1) * st + ks - h, 0) // 2; a.PL = max((ow - 1) * st + ks - w, 0) // 2
+    a.K, a.Kp, a.Np, a.ldr1, a.pre_relu = ks * ks * cin, kp, np_, cout, int(relu)
+    assert hip_lib.dh_conv2d_uses_split_k(C.byref(a)) == 1
+    assert hip_lib.dh_conv2d_f32(C.byref(a), -1, torch.cuda.current_stream().cuda_stream) == 0
+    torch.cuda.synchronize()
+    assert torch.equal(y, got)
+    a.K = 288; a.Cin = 288; a.KH = a.KW = 1                                   # an MPII 16 x 16 pointwise conv: not skinny
+    assert hip_lib.dh_conv2d_uses_split_k(C.byref(a)) == 0
 
 
 @pytest.mark.parametrize('case', SPLIT_CASES)
