@@ -22,8 +22,20 @@ for CFG in 11 12; do
   [ -n "$DB" ] && python tools/rocpd_stats.py pmc $DB gemm1x1 >> $OUT/${TAG}_pmc_summary.txt
  done
 done
-cat $OUT/${TAG}_pmc_summary.txt
+# split-bf16 mode: kernel stats of the same bench in bf16x3 mode (one graph branch) and the PMC passes of the wide tiling
+B3="--gemm bf16x3 --no-cpu-baseline --no-predict --no-clip-leg --no-bf16x3 --tune-cache $OUT/${TAG}_tune_bf16x3.json"
+python bench.py $B3 --steps 10 > $OUT/${TAG}_b3.log 2>&1
+(cd /tmp && rocprofv3 --kernel-trace --stats -d $OUT/${TAG}_prof_b3 -o out -- python $GRAFT_REPO_ROOT/bench.py $B3 --steps 20 --warmup 3 --streams 1 > $OUT/${TAG}_prof_b3.log 2>&1)
+DB=$(ls $OUT/${TAG}_prof_b3/*/*results.db $OUT/${TAG}_prof_b3/*results.db 2>/dev/null | head -1)
+[ -n "$DB" ] && python tools/rocpd_stats.py kernels $DB $OUT/${TAG}_bench_kernel_stats_bf16x3_streams1.csv
+for C in FETCH_SIZE WRITE_SIZE SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE; do
+  (cd /tmp && rocprofv3 --pmc $C --kernel-trace -d $OUT/${TAG}_pmc_w_$C -o out -- python $GRAFT_REPO_ROOT/tools/bench_one.py 32 576 576 1 1 14 4 0 1 > /dev/null 2>&1)
+  DB=$(ls $OUT/${TAG}_pmc_w_$C/*/*results.db $OUT/${TAG}_pmc_w_$C/*results.db 2>/dev/null | head -1)
+  [ -n "$DB" ] && python tools/rocpd_stats.py pmc $DB gemm1x1s_wide >> $OUT/${TAG}_pmc_summary_bf16x3.txt
+done
+cat $OUT/${TAG}_pmc_summary.txt $OUT/${TAG}_pmc_summary_bf16x3.txt
+tail -1 $OUT/${TAG}_prof_b3.log | cut -c1-300
 tail -1 $OUT/${TAG}_prof_s2.log | cut -c1-400
 head -12 $OUT/${TAG}_bench_kernel_stats_streams2.csv
 # keep the merged-back payload small
-rm -rf $OUT/${TAG}_prof_s1 $OUT/${TAG}_prof_s2 $OUT/${TAG}_pmc_1*
+rm -rf $OUT/${TAG}_prof_s1 $OUT/${TAG}_prof_s2 $OUT/${TAG}_prof_b3 $OUT/${TAG}_pmc_1* $OUT/${TAG}_pmc_w_*
