@@ -5,8 +5,10 @@
 //   a b ~ a3 b1 + a1 b3 + a2 b2 + a2 b1 + a1 b2 + a1 b1          (dropped: a2 b3 + a3 b2 + a3 b3 <= 2^-23 |a b|)
 // accumulated in fp32 inside v_mfma_f32_32x32x16_bf16.  Six bf16 MFMAs cover 16 k-values in 6 x 32 = 192 cycles per
 // SIMD; the fp32 MFMA (v_mfma_f32_32x32x2_f32, vector rate) needs 8 x 64 = 512 -- and, unlike the fp32 MFMA, the bf16
-// MFMA leaves the SIMD's other issue ports free, so the splitting VALU work and the LDS reads run underneath it
-// (profiles/r02_sepconv_fusion_study.md section 3 for the fp32 side of that statement).
+// MFMA lets about four VALU instructions per MFMA issue underneath it (LDS reads and DMA pieces do not hide): the K loops
+// below are arranged around that budget (profiles/r02_sepconv_fusion_study.md section 3, profiles/r02_split_loop_model.txt).
+// The nominal 2.5 PFLOP/s is only sustained on constant operands; on real data the bf16 cores run at ~1.9 PFLOP/s
+// (profiles/r02_mfma_data_power.txt).
 // The per-product error (2^-23 relative, typically 2^-25) is below what the fp32 accumulation itself contributes
 // (sqrt(K) roundings of the running sum), so results stay within the same 1e-3 px of the fp64 oracle
 // (profiles/parity_r02_bf16x3.json); they are NOT bit-identical to the fp32-MFMA path, which remains the default.
