@@ -143,6 +143,12 @@ class _InputStep:
         return 5 * n * int(np.prod(v.shape))
 
 
+def split_k_rule(out_pixels, K, cout, cin):
+    """Mirror of conv_is_skinny (csrc/conv_splitk.hip; dh_conv2d_uses_split_k): the layers dh_conv2d_f32 runs on its
+    in-work-group split-K kernel -- per-frame geometry only, so a layer's bits depend on neither batch size nor tiling."""
+    return out_pixels <= 256 and K >= 768 and cout <= 256 and cin % 4 == 0
+
+
 class BoundPlan:
     """A Plan with concrete device pointers for batch size n."""
 
@@ -190,9 +196,8 @@ class BoundPlan:
             return False
         y = s.outs['y']
         up = 2 if a['up2'] else 1
-        # tiny per-frame output + long reduction: the split-K kernel (fp32 weights; conv_splitk.hip conv_is_skinny)
-        if (y.shape[-3] // up) * (y.shape[-2] // up) <= 256 and a['kh'] * a['kw'] * a['Cin'] >= 768 and y.C <= 256 and \
-                a['Cin'] % 4 == 0:
+        # tiny per-frame output + long reduction: the split-K kernel, which reads fp32-packed weights
+        if split_k_rule((y.shape[-3] // up) * (y.shape[-2] // up), a['kh'] * a['kw'] * a['Cin'], y.C, a['Cin']):
             return False
         same = x.shape[-3] == y.shape[-3] // up and x.shape[-2] == y.shape[-2] // up
         pointwise = a['kh'] == a['kw'] == 1 and a['sh'] == a['sw'] == 1 and a['pt'] == a['pl'] == 0 and same and \

@@ -291,3 +291,25 @@ def test_multi_stream_memory_plan_is_race_free(nstreams):
         for w in s.wait:
             assert w < j and stream[w] != stream[j] and plan.steps[w].record
         assert set(s.wait) <= set(deps[j])
+
+
+def test_split_k_rule_matches_the_library(hip_lib):
+    """engine.executor.split_k_rule (decides which weight packing a layer gets in bf16x3 mode) must agree with the
+    library's own dispatch rule dh_conv2d_uses_split_k for every geometry."""
+    import ctypes as C
+    from deephar_amd import _lib
+    from deephar_amd.engine.executor import split_k_rule
+    a = _lib.ConvArgs()
+    n = 0
+    for oh, ow in ((4, 4), (16, 16), (16, 10), (8, 5), (17, 16), (32, 32), (1, 1)):
+        for k in (1, 3, 5):
+            for cin in (3, 30, 48, 112, 256, 288, 576, 1024):
+                for cout in (15, 48, 256, 257, 576):
+                    a.N, a.OH, a.OW, a.Cin, a.Cout, a.KH, a.KW, a.K = 3, oh, ow, cin, cout, k, k, k * k * cin
+                    a.x_u8 = a.w_split = 0
+                    assert bool(hip_lib.dh_conv2d_uses_split_k(C.byref(a))) == split_k_rule(oh * ow, k * k * cin, cout, cin), \
+                        (oh, ow, k, cin, cout)
+                    n += 1
+    a.w_split = 1
+    assert hip_lib.dh_conv2d_uses_split_k(C.byref(a)) == 0            # split-packed weights never take that kernel
+    assert n > 500
