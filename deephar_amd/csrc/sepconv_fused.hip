@@ -354,6 +354,7 @@ int sepconv_pick_cfg(int M, int Cout) {
 int launch_sepconv_fused(const ConvArgs& a, const float* dw, int dkh, int dkw, int dpt, int dpl, int cfg,
                          hipStream_t s) {
   if (dw == nullptr || a.N <= 0 || a.Cin <= 0 || a.Cout <= 0) return DH_EINVAL;
+  if (a.y_pool != nullptr) return DH_EUNSUPPORTED;     // (the pooled second output lives in the shared LDS-slab epilogue)
   const int ks = dkh;
   const bool shape = dkh == dkw && (ks == 5 || ks == 3) && dpt == (ks - 1) / 2 && dpl == (ks - 1) / 2 &&
                      a.KH == 1 && a.KW == 1 && a.SH == 1 && a.SW == 1 && a.PT == 0 && a.PL == 0 && a.H == a.OH &&

@@ -19,6 +19,8 @@ Fusion rules (what the reference leaves to TensorFlow as separate kernels):
                 maps are one soft-argmax kernel (blocks.py:306-343).
 All tensors are fp32; sizes are tracked per batch item so one plan serves any batch size.
 """
+import os
+
 import numpy as np
 
 from .. import graph as G
@@ -58,6 +60,12 @@ class Value:
     def lead(self, nd):
         """product of the dims in front of the last `nd` dims (folded into the batch)."""
         return int(np.prod(self.shape[:-nd])) if len(self.shape) > nd else 1
+
+
+def split_k_rule(out_pixels, K, cout, cin):
+    """Mirror of conv_is_skinny (csrc/conv_splitk.hip; dh_conv2d_uses_split_k): the layers dh_conv2d_f32 runs on its
+    in-work-group split-K kernel -- per-frame geometry only, so a layer's bits depend on neither batch size nor tiling."""
+    return out_pixels <= 256 and K >= 768 and cout <= 256 and cin % 4 == 0
 
 
 class Step:
@@ -133,6 +141,8 @@ class Planner:
         # pointwise GEMM).  Bit-identical to the two-launch pair but measured 7-40 % SLOWER on gfx950: the fp32 MFMA
         # leaves no issue slots for the depthwise stage (profiles/r02_sepconv_fusion_study.md), so it is off by default.
         self.fuse_sepconv = _fuse_sepconv_default() if fuse_sepconv is None else bool(fuse_sepconv)
+        self.fuse_pool = os.environ.get('DEEPHAR_FUSE_POOL', '0') not in ('0', '')      # R7, off by default (see op_pool)
+        self.producer = {}            # id(Value) -> the Step that writes it
         self.g_inputs = inputs
         self.g_outputs = outputs
         self.nodes = G.topo_nodes(outputs)
@@ -178,6 +188,9 @@ class Planner:
     def emit(self, kind, ins, outs, attrs=None, params=None, name=None):
         s = Step(kind, ins, outs, attrs, params, name)
         self.plan.steps.append(s)
+        for v in outs.values():
+            if v is not None:
+                self.producer[id(v)] = s
         return s
 
     def available(self, t):
@@ -422,6 +435,25 @@ class Planner:
     def op_pool(self, node):
         x = self.materialize(node.inputs[0])
         y = self.out_value_for(node.outputs[0])
+        # R7 (DEEPHAR_FUSE_POOL=1): MaxPooling2D((2, 2)) of a convolution's output at 32 columns is written by that
+        # convolution's epilogue as a second output (dh_conv_args.y_pool) -- the stand-alone pool reads the whole tensor
+        # back from HBM (reception.py:105-116: every hourglass level is used at full AND at half resolution).
+        # Bit-identical, but measured neutral on the MPII model (4 834 vs 4 846 frames/s): in seven of eight blocks the
+        # producer is the K = 48 fReMap GEMM, itself bound by its epilogue, and the pooling pass costs it what the pool
+        # kernel cost.  Off by default.
+        a = node.attrs
+        prod = self.producer.get(id(x))
+        if self.fuse_pool and prod is not None and prod.kind == 'conv' and prod.outs.get('y') is x and \
+                'ypool' not in prod.outs and not prod.attrs.get('up2') and a.get('mode', 0) == 0 and \
+                (a['kh'], a['kw'], a['sh'], a['sw'], a['pt'], a['pl']) == (2, 2, 2, 2, 0, 0) and \
+                x.shape[-2] == 32 and x.shape[-3] % 2 == 0 and x.C % 4 == 0 and x.ld % 4 == 0 and y.ld % 4 == 0 and \
+                x.coff % 4 == 0 and y.coff % 4 == 0 and \
+                not split_k_rule(x.shape[-3] * x.shape[-2], prod.attrs['K'], prod.attrs['Cout'], prod.attrs['Cin']):
+            prod.outs['ypool'] = y
+            prod.attrs['pool2'] = 1
+            self.producer[id(y)] = prod
+            self.val[node.outputs[0].uid] = y
+            return
         self.emit('pool', dict(x=x), dict(y=y), dict(node.attrs), name=node.name or 'pool')
         self.val[node.outputs[0].uid] = y
 
