@@ -338,3 +338,15 @@ def test_split_k_rule_matches_the_library(hip_lib):
     a.w_split = 1
     assert hip_lib.dh_conv2d_uses_split_k(C.byref(a)) == 0            # split-packed weights never take that kernel
     assert n > 500
+
+
+def test_integration_guide_declares_the_whole_conv_struct():
+    """The ctypes example of INTEGRATION.md is what a maintainer copies: its ConvArgs must list every field of
+    dh_conv_args, in order (a shorter struct makes the library read garbage for the tail)."""
+    import re
+    from deephar_amd import _lib
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    doc = open(os.path.join(root, 'INTEGRATION.md')).read()
+    block = doc[doc.index('class ConvArgs(C.Structure)'):doc.index('lib.dh_conv2d_f32.argtypes')]
+    names = re.findall(r"'([A-Za-z_0-9]+)'", block)
+    assert names == [n for n, _ in _lib.ConvArgs._fields_]
