@@ -243,7 +243,12 @@ def roofline(rows, kinds, total_flops_per_step, ms_per_step):
     extra = {'kernel_time_share': {k: round(v['ms'] / eager_total_ms, 4) for k, v in sorted(kinds.items())},
              'hbm_bound_kernels': {k: {'GBps': round(v['bytes'] / (v['ms'] * 1e-3) / 1e9, 1),
                                        'frac_of_8TBps': round(v['bytes'] / (v['ms'] * 1e-3) / 1e9 / PEAK_HBM_GBS, 4)}
-                                   for k, v in sorted(kinds.items()) if k in ('dwconv', 'pool', 'sam') and v['ms'] > 0}}
+                                   for k, v in sorted(kinds.items()) if k in ('dwconv', 'pool') and v['ms'] > 0},
+             # (includes the 16x16 / 8x8 levels, whose 5-38 MB launches are latency-, not bandwidth-bound; the 32x32 depthwise
+             #  runs at 4.3-4.5 TB/s, torch's copy_ of the same tensor at 5.1: tools/micro/hbm_copy.py)
+             'latency_bound_kernels': {k: {'launches': v['launches'], 'avg_us': round(1e3 * v['ms'] / v['launches'], 1),
+                                           'MB_per_launch': round(v['bytes'] / v['launches'] / 1e6, 2)}
+                                       for k, v in sorted(kinds.items()) if k in ('sam', 'context_agg') and v['ms'] > 0}}
     return out, extra
 
 
