@@ -72,7 +72,7 @@ def entry_flow(W, x, growth=96, image_div=8):
 
 
 def prediction_branch(W, x, num_joints, name, pred_activate=True, forward_maps=True, reinject=True,
-                      replica=False):
+                      replica=False, taps=None):
     """spnet.prediction_branch (spnet.py:24-48).  `replica` (spnet.py:36-38): a second, independently weighted
     1x1 conv '<name>_conv1_replica' on the same activated input; its maps feed the ACTION stream only
     (spnet.py:216,224), the pose stream and the re-injection keep using '<name>_conv1'.
@@ -81,6 +81,8 @@ def prediction_branch(W, x, num_joints, name, pred_activate=True, forward_maps=T
     Returns (re-injected features | None, prediction maps, replica maps | None)."""
     nf = x.shape[-1]
     x = ops.relu(x)
+    if taps is not None and taps.get('want_head_inputs'):
+        taps[name + '/in'] = x.numpy().copy()        # what the 1x1 heads read (tests/wellcond.py fits heads on it)
     pred_maps = _conv(W, x, num_joints, (1, 1), name + '_conv1')
     rep = _conv(W, x, num_joints, (1, 1), name + '_conv1_replica') if replica else None
     if not reinject:
@@ -157,7 +159,8 @@ def forward(weights, clips, cfg, dtype=torch.float32, taps=None):
     num_levels, kernel_size, growth, image_div, num_pose_features, num_visual_features, sam_alpha
     [, pose_replica=False]).
     taps: optional dict, filled with '<prediction block>/logits' = heat-map logits [N*T, h, w, J] and, for 3-D
-    models, '<prediction block>/dlogits' = depth-map logits (numpy).
+    models, '<prediction block>/dlogits' = depth-map logits (numpy); when it already holds a true
+    'want_head_inputs', also '<prediction block>_heatmaps/in' = the activated tensor the 1x1 heads read.
     clips: [N, T, H, W, 3] (or [N, H, W, 3]).  Returns poses [N,(T,)J,dim+1] ... then action scores [N, A] ..."""
     W = weights if isinstance(weights, Weights) else Weights(weights, dtype)
     W.reset()
@@ -183,7 +186,7 @@ def forward(weights, clips, cfg, dtype=torch.float32, taps=None):
             xp = _bn(W, xp, name + '_bn2')
             replica = bool(cfg.get('pose_replica', False)) and do_action          # spnet.py:160
             x1, org_h, rep_h = prediction_branch(W, xp, J, name + '_heatmaps', pred_activate=True,
-                                                 reinject=not last_pose, replica=replica)
+                                                 reinject=not last_pose, replica=replica, taps=taps)
             reinject.append(x1)
             if taps is not None:
                 taps[name + '/logits'] = org_h.numpy().copy()

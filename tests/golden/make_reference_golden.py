@@ -8,7 +8,10 @@ reference names its layers, by creation order inside each nested Model otherwise
 load_weights uses), so a wiring or ordering difference between the product builders and the reference shows up
 either as a shape mismatch here or as a numeric mismatch in tests/test_reference_golden.py.
 
-    python tests/golden/make_reference_golden.py        ->  tests/golden/reference_models.npz
+    python tests/golden/make_reference_golden.py            ->  tests/golden/reference_models.npz
+    python tests/golden/make_reference_golden.py --smooth   ->  tests/golden/reference_models_smooth.npz
+        (SPNet on the well-conditioned vectors of tests/wellcond.py: video clips + heat-map heads fitted on the
+         oracle; the fitted head kernels are stored beside the outputs, '<tag>/head/<layer name>')
 """
 import importlib
 import os
@@ -20,6 +23,7 @@ import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, 'tests'))
 REF = '/root/reference'
 OUT = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'reference_models.npz')
 
@@ -109,6 +113,8 @@ def draw(tag, shape):
 
 
 TAGS = ('rec2d', 'rec3d', 'merge2d', 'merge3d', 'spnet3d', 'spnet2d', 'spnet2dr')
+SMOOTH_TAGS = ('spnet3d_s', 'spnet2d_s', 'spnet2dr_s')
+OUT_SMOOTH = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'reference_models_smooth.npz')
 
 
 def build_pair(R, tag):
@@ -146,9 +152,11 @@ def build_pair(R, tag):
     # SPNet: NTU-like 3-D (T=4, time_stride 1), Penn-like 2-D (T=16, time_stride 2, frame/joint padding) and the
     # shipped PennAction multitask configuration (exp/pennaction/eval_penn_multitask.py:36-40: T=8, 6 pyramids,
     # actions on pyramids 5 and 6, pose_replica=True -> '<pb>_heatmaps_conv1_replica' feeds the action stream)
+    smooth = tag.endswith('_s')
     T, lay, nact, pyr, apyr, feats, res, rep = {'spnet3d': (4, 'pa17j3d', 60, 2, [1, 2], 192, 128, False),
                                                 'spnet2d': (16, 'pa16j2d', 15, 2, [2], 160, 128, False),
-                                                'spnet2dr': (8, 'pa16j2d', 15, 6, [5, 6], 160, 128, True)}[tag]
+                                                'spnet2dr': (8, 'pa16j2d', 15, 6, [5, 6], 160, 128, True)}[
+        tag[:-2] if smooth else tag]
     R['models.spnet'].__dict__.pop('act_cnt', None)       # the reference's process-global counter
     rcfg = R['config'].ModelConfig((T, res, res, 3), getattr(putils, lay), num_actions=[nact], num_pyramids=pyr,
                                    action_pyramids=apyr, num_levels=4, pose_replica=rep,
@@ -158,6 +166,9 @@ def build_pair(R, tag):
                                action_pyramids=apyr, num_levels=4, pose_replica=rep, num_pose_features=feats,
                                num_visual_features=feats)
     prod = pspn.build(pcfg)
+    if smooth:
+        import refgolden
+        return ref, prod, refgolden.smooth_input(tag, res)[0].astype(np.float64)
     return ref, prod, draw(tag, (1, T, res, res, 3))
 
 
@@ -212,15 +223,22 @@ def check_weight_files(tag, ref_model, product_model):
           ('by name' if by_name else 'by order', 'n/a (by-name family)' if by_name else 'by order'))
 
 
-def main():
+def main(smooth=False):
     import json
     from deephar_amd import weights
     R = load_reference()
     g = {}
     layouts = {}
-    for tag in TAGS:
+    for tag in (SMOOTH_TAGS if smooth else TAGS):
         ref_model, product_model, x = build_pair(R, tag)
         weights.init_synthetic(product_model, seed=0)
+        if smooth:
+            import refgolden
+            import wellcond
+            heads = wellcond.fit_spnet_heads(product_model, refgolden.spnet_ocfg(tag), x.astype(np.float32),
+                                             refgolden.smooth_input(tag)[1])
+            for name, k in heads.items():
+                g['%s/head/%s' % (tag, name)] = k
         n = transfer_weights(product_model, ref_model)
         assert n == len(product_model.params), (tag, n, len(product_model.params))
         layouts[tag] = keras_file_layout(ref_model)
@@ -231,11 +249,13 @@ def main():
                 g['%s/%s/%d' % (tag, k, i)] = a.astype(np.float64 if k == 'f64' else np.float32)
         g['%s/nout' % tag] = np.array(len(outs['f64']))
         print(tag, 'outputs', [a.shape for a in outs['f64']], 'weights set', n)
-    with open(os.path.join(os.path.dirname(OUT), 'keras_layouts.json'), 'w') as fh:
-        json.dump(layouts, fh, separators=(',', ':'))
-    np.savez_compressed(OUT, **g)
-    print('wrote', OUT, '%.1f MB' % (os.path.getsize(OUT) / 1e6))
+    out = OUT_SMOOTH if smooth else OUT
+    if not smooth:
+        with open(os.path.join(os.path.dirname(OUT), 'keras_layouts.json'), 'w') as fh:
+            json.dump(layouts, fh, separators=(',', ':'))
+    np.savez_compressed(out, **g)
+    print('wrote', out, '%.1f MB' % (os.path.getsize(out) / 1e6))
 
 
 if __name__ == '__main__':
-    main()
+    main(smooth='--smooth' in sys.argv)

@@ -1,10 +1,20 @@
 """Shared description of the golden cases produced by tests/golden/make_reference_golden.py (the reference's own
 model code executed on oracle/refrun/minikeras.py in the build container)."""
 import os
+import sys
 
 import numpy as np
 
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'reference_models.npz')
+# the '<tag>_s' cases: SPNet on well-conditioned vectors (tests/wellcond.py: video clips + fitted heat-map heads);
+# the fitted head kernels travel with the outputs, so a test rebuilds exactly the weights the reference code ran on
+GOLDEN_SMOOTH = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'reference_models_smooth.npz')
+SPNET_CASES = {'spnet3d': (4, 'pa17j3d', 60, 2, [1, 2], 192, False),
+               'spnet2d': (16, 'pa16j2d', 15, 2, [2], 160, False),
+               'spnet2dr': (8, 'pa16j2d', 15, 6, [5, 6], 160, True)}
+SMOOTH_SEED = 31
 
 
 def case_input(tag, shape):
@@ -12,8 +22,27 @@ def case_input(tag, shape):
     return np.random.default_rng(seed).uniform(-1, 1, shape)
 
 
+def smooth_input(tag, res=128):
+    """(clips float32 [1, T, res, res, 3], peak positions [T, J, 2]) of a '<tag>_s' case."""
+    import wellcond
+    from deephar_amd import utils
+    T, lay = SPNET_CASES[tag[:-2]][:2]
+    J = getattr(utils, lay).num_joints
+    seed = SMOOTH_SEED + sorted(SPNET_CASES).index(tag[:-2])
+    return wellcond.video_clips(1, T, res, seed), wellcond.joint_positions(1, T, J, seed)
+
+
+def spnet_ocfg(tag):
+    from deephar_amd import utils
+    T, lay, nact, pyr, apyr, feats, rep = SPNET_CASES[tag[:-2] if tag.endswith('_s') else tag]
+    layout = getattr(utils, lay)
+    return dict(num_joints=layout.num_joints, dim=layout.dim, num_actions=[nact], num_pyramids=pyr,
+                action_pyramids=apyr, num_levels=4, kernel_size=(5, 5), growth=96, image_div=8,
+                num_pose_features=feats, num_visual_features=feats, sam_alpha=1, pose_replica=rep)
+
+
 def golden(tag):
-    g = np.load(GOLDEN)
+    g = np.load(GOLDEN_SMOOTH if tag.endswith('_s') else GOLDEN)
     n = int(g['%s/nout' % tag])
     return [g['%s/f32/%d' % (tag, i)] for i in range(n)], [g['%s/f64/%d' % (tag, i)] for i in range(n)]
 
@@ -47,24 +76,26 @@ def build_case(tag):
         okw = dict(pose_dim=dim, depth_maps=8, pose_net_version=ver, output_poses=True,
                    num_context_per_joint=2 if dim == 2 else 0)
         run = lambda wd, dt: oact.forward_merge(wd, x, 15, J, 2, dtype=dt, **okw)
-    elif tag in ('spnet3d', 'spnet2d', 'spnet2dr'):
-        T, lay, nact, pyr, apyr, feats, rep = {'spnet3d': (4, 'pa17j3d', 60, 2, [1, 2], 192, False),
-                                               'spnet2d': (16, 'pa16j2d', 15, 2, [2], 160, False),
-                                               'spnet2dr': (8, 'pa16j2d', 15, 6, [5, 6], 160, True)}[tag]
+    elif tag in SPNET_CASES or (tag.endswith('_s') and tag[:-2] in SPNET_CASES):
+        T, lay, nact, pyr, apyr, feats, rep = SPNET_CASES[tag[:-2] if tag.endswith('_s') else tag]
         layout = getattr(utils, lay)
         cfg = ModelConfig((T, 128, 128, 3), layout, num_actions=[nact], num_pyramids=pyr, action_pyramids=apyr,
                           num_levels=4, pose_replica=rep, num_pose_features=feats, num_visual_features=feats)
         m = spnet.build(cfg)
-        x = case_input(tag, (1, T, 128, 128, 3))
-        ocfg = dict(num_joints=layout.num_joints, dim=layout.dim, num_actions=[nact], num_pyramids=pyr,
-                    action_pyramids=apyr, num_levels=4, kernel_size=(5, 5), growth=96, image_div=8,
-                    num_pose_features=feats, num_visual_features=feats, sam_alpha=1, pose_replica=rep)
+        x = smooth_input(tag)[0] if tag.endswith('_s') else case_input(tag, (1, T, 128, 128, 3))
+        ocfg = spnet_ocfg(tag)
         run = lambda wd, dt, taps=None: osp.forward(wd, x, ocfg, dtype=dt, taps=taps)
     else:
         raise KeyError(tag)
     weights.init_synthetic(m, seed=0)
+    if tag.endswith('_s'):
+        import wellcond
+        g = np.load(GOLDEN_SMOOTH)
+        pre = '%s/head/' % tag
+        wellcond.apply_heads(m, {k[len(pre):]: g[k] for k in g.files if k.startswith(pre)})
     wd = weights.as_dict(m)
     return m, x, (lambda dt, **kw: run(wd, dt, **kw))
 
 
 CASES = ['rec2d', 'rec3d', 'merge2d', 'merge3d', 'spnet3d', 'spnet2d', 'spnet2dr']
+SMOOTH_CASES = ['spnet3d_s', 'spnet2d_s', 'spnet2dr_s']

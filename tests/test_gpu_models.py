@@ -3,9 +3,10 @@ on identical seeded weights and inputs, plus size-independent properties at the 
 
 Tolerance (BASELINE.json north_star): joint coordinates within 1e-3 px of a 256-px crop, i.e.
 |d| <= 3.9e-6 in the model's normalised [0,1] output, asserted as max|hip - oracle_fp64| <= 1e-3 px with no
-relative clause (tests/paritylog.py; every comparison also lands in gpurun_out/parity_r02.json together with
-|oracle_fp32 - oracle_fp64| and |hip - oracle_fp32|).  SPNet's synthetic heat-maps are the one place where the
-read-out itself is ill-conditioned; see paritylog.conditioned_tolerance for the a-priori bound used there.
+relative clause (tests/paritylog.py; every comparison also lands in gpurun_out/parity_r03.json together with
+|oracle_fp32 - oracle_fp64| and |hip - oracle_fp32|).  SPNet on per-pixel-noise inputs is the one place where the
+synthetic read-out itself is ill-conditioned: those cases are kept here as a stress test under
+paritylog.conditioned_tolerance; SPNet at the flat 1e-3 px bar lives in tests/test_gpu_spnet_flat.py.
 """
 import os
 import sys
@@ -342,8 +343,10 @@ def test_frame_sharded_stages_match_full_model(hip_lib, cuda):
 @pytest.mark.parametrize('tag', ['rec2d', 'rec3d', 'merge2d', 'merge3d', 'spnet3d', 'spnet2d', 'spnet2dr'])
 def test_hip_matches_reference_code_goldens(tag, hip_lib, cuda):
     """HIP engine vs the committed golden vectors that were computed by the reference's OWN model code
-    (tests/golden/make_reference_golden.py): coordinates within max(1e-3 px, 3 x the fp32 error of that same code),
-    identical arg-max action labels."""
+    (tests/golden/make_reference_golden.py): coordinates within a flat 1e-3 px of the reference code's fp64 run,
+    identical arg-max action labels.  The three SPNet goldens here were made on per-pixel-noise inputs with
+    un-calibrated heads (multi-modal maps, |logit| up to 100) and are kept as a STRESS case under
+    paritylog.conditioned_tolerance; SPNet at the flat bar is tests/test_gpu_spnet_flat.py."""
     import sys, os
     sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
     from refgolden import build_case, golden

@@ -1,0 +1,105 @@
+"""SPNet at the FLAT 1e-3 px bar (reference deephar/models/spnet.py:151-248).
+
+Vectors: tests/wellcond.py -- video clips of low-pass noise and heat-map heads fitted on the oracle so that every
+prediction block has one peak per joint (read-out sensitivity S = sum p |g - x| <= 0.05, asserted from the fp64
+oracle's logits; maps not one-hot).  Checks: plain `paritylog.check(..., PX_TOL)` on x/y (and z) of every prediction
+block -- no conditioned tolerance, no relative clause -- in the default fp32-MFMA mode and in the opt-in bf16x3
+mode, `hip - o32` recorded beside `hip - o64`; confidences to 1e-5 absolute, action scores to 1e-5, identical labels.
+
+Configurations at the real 256x256 resolution:
+  ntu3d_T8        exp/ntu/eval_ntu_multitask.py:35-38 (pa17j3d, 60 actions, 2 pyramids, T = 8)
+  penn2d_T16      2-D, T = 16 (time_stride 2 branch, spnet.py:100), action on pyramid 2
+  penn_shipped    exp/pennaction/eval_penn_multitask.py:36-40: 6 pyramids, actions on 5 and 6, pose_replica=True
+  cfg5_ntu_T32    BASELINE.json configs[4]: the NTU model at T = 32
+and the three reference-code goldens 'spnet3d_s', 'spnet2d_s', 'spnet2dr_s' (the reference's own spnet.py run on the
+same kind of vectors, tests/golden/make_reference_golden.py --smooth).
+"""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import paritylog                                   # noqa: E402
+import wellcond                                    # noqa: E402
+from paritylog import PX_TOL, check                # noqa: E402
+
+pytestmark = pytest.mark.gpu
+
+CONFIGS = {
+    'ntu3d_T8': (8, 'pa17j3d', 60, 2, [1, 2], 192, False),
+    'penn2d_T16': (16, 'pa16j2d', 15, 2, [2], 160, False),
+    'penn_shipped': (8, 'pa16j2d', 15, 6, [5, 6], 160, True),
+    'cfg5_ntu_T32': (32, 'pa17j3d', 60, 2, [1, 2], 192, False),
+}
+_CACHE = {}
+
+
+def _prepare(name):
+    """Model with fitted heads + clips + fp32 / fp64 oracle outputs; shared by the two GEMM modes of a configuration."""
+    if name in _CACHE:
+        return _CACHE[name]
+    from test_gpu_models import _spnet
+    from deephar_amd import weights
+    from oracle import spnet as osp
+    T, layout, nact, pyr, apyr, feats, replica = CONFIGS[name]
+    seed = 40 + sorted(CONFIGS).index(name)
+    x = wellcond.video_clips(1, T, 256, seed)
+    m, cfg, _, ocfg = _spnet(T, layout, nact, pyr, apyr, feats, replica=replica)
+    wellcond.fit_spnet_heads(m, ocfg, x, wellcond.joint_positions(1, T, ocfg['num_joints'], seed))
+    wd = weights.as_dict(m)
+    t64 = {}
+    o32 = osp.forward(wd, x, ocfg, dtype=torch.float32)
+    o64 = osp.forward(wd, x, ocfg, dtype=torch.float64, taps=t64)
+    stats = wellcond.assert_well_conditioned(t64, name)
+    _CACHE.clear()                                  # one configuration at a time (a T = 32 clip is 25 MB, fine; models are not)
+    _CACHE[name] = (m, x, ocfg, o32, o64, stats, (pyr, apyr))
+    return _CACHE[name]
+
+
+def _flat_checks(tag, hip, o32, o64, dim, npose, case):
+    flat = lambda a: a.reshape((-1,) + a.shape[-2:])
+    for k in range(npose):
+        h, a, b = flat(hip[k]), flat(o32[k]), flat(o64[k])
+        check('%s.out%d.xy' % (tag, k), h[..., :2], a[..., :2], b[..., :2], PX_TOL, case=case)
+        if dim == 3:
+            check('%s.out%d.z' % (tag, k), h[..., 2], a[..., 2], b[..., 2], PX_TOL, case=case)
+        check('%s.out%d.conf' % (tag, k), h[..., dim], a[..., dim], b[..., dim], 1e-5, case=case)
+    for k in range(npose, len(hip)):
+        check('%s.act%d' % (tag, k - npose), hip[k], o32[k], o64[k], 1e-5, case=case)
+        assert np.array_equal(hip[k].argmax(-1), o64[k].argmax(-1)), '%s: action label differs on head %d' % (tag, k - npose)
+
+
+@pytest.mark.parametrize('mode', ['f32', 'bf16x3'])
+@pytest.mark.parametrize('name', list(CONFIGS))
+def test_spnet_flat_1e3_px(name, mode, hip_lib, cuda):
+    from deephar_amd.models import spnet
+    m, x, ocfg, o32, o64, stats, (pyr, apyr) = _prepare(name)
+    m.gemm_precision = mode
+    hip = m.predict(x, batch_size=1)
+    npose = spnet.get_num_predictions(pyr, 4)
+    assert len(hip) == npose + spnet.get_num_predictions(len(apyr), 4)
+    assert [h.shape for h in hip] == [o.shape for o in o64]
+    print('%s: S_max per block %s' % (name, ' '.join('%.3f' % s['S_max'] for s in stats.values())))
+    _flat_checks('%s.%s' % (name, mode), hip, o32, o64, ocfg['dim'], npose, case='spnet_flat/%s/%s' % (name, mode))
+
+
+@pytest.mark.parametrize('mode', ['f32', 'bf16x3'])
+@pytest.mark.parametrize('tag', ['spnet3d_s', 'spnet2d_s', 'spnet2dr_s'])
+def test_hip_matches_smooth_reference_code_goldens(tag, mode, hip_lib, cuda):
+    """HIP engine vs golden vectors computed by the reference's OWN spnet.py / common.py / layers.py (on mini-Keras) for
+    the well-conditioned vectors: flat 1e-3 px on every pose output, identical arg-max action labels."""
+    from refgolden import build_case, golden
+    m, x, run = build_case(tag)
+    t64 = {}
+    run(torch.float64, taps=t64)
+    wellcond.assert_well_conditioned(t64, tag)
+    g32, g64 = golden(tag)
+    m.gemm_precision = mode
+    hip = m.predict(x.astype(np.float32), batch_size=len(x))
+    assert [h.shape for h in hip] == [g.shape for g in g64]
+    npose = sum(1 for g in g64 if g.ndim == 4)
+    _flat_checks('%s.%s' % (tag, mode), hip, g32, g64, g64[0].shape[-1] - 1, npose,
+                 case='spnet_flat_golden/%s/%s' % (tag, mode))

@@ -8,10 +8,10 @@ import numpy as np
 import pytest
 import torch
 
-from refgolden import CASES, build_case, golden
+from refgolden import CASES, SMOOTH_CASES, build_case, golden
 
 
-@pytest.mark.parametrize('tag', CASES)
+@pytest.mark.parametrize('tag', CASES + SMOOTH_CASES)
 def test_oracle_matches_reference_code(tag):
     _, _, run = build_case(tag)
     g32, g64 = golden(tag)
@@ -23,6 +23,24 @@ def test_oracle_matches_reference_code(tag):
     o32 = run(torch.float32)
     for k, (a, b) in enumerate(zip(o32, g32)):
         assert np.abs(a - b).max() <= 2e-5 * max(1.0, np.abs(b).max()), (tag, k, np.abs(a - b).max())
+
+
+@pytest.mark.parametrize('tag', SMOOTH_CASES)
+def test_smooth_goldens_are_well_conditioned(tag):
+    """The '<tag>_s' goldens (reference code on tests/wellcond.py vectors) are what the flat 1e-3 px SPNet tests stand
+    on: every prediction block's read-out sensitivity S <= 0.05, maps not one-hot, and plain fp32 arithmetic (the
+    reference code's own fp32 run) within 1e-3 px of its fp64 run -- i.e. these vectors can resolve the bar."""
+    import wellcond
+    _, _, run = build_case(tag)
+    t64 = {}
+    run(torch.float64, taps=t64)
+    stats = wellcond.assert_well_conditioned(t64, tag)
+    assert len(stats) in (6, 18)
+    g32, g64 = golden(tag)
+    for a, b in zip(g32, g64):
+        if b.ndim == 4:          # poses [1, T, J, dim + 1]
+            d = b.shape[-1] - 1
+            assert 256.0 * np.abs(a[..., :d] - b[..., :d]).max() <= 1e-3, tag
 
 
 @pytest.mark.skipif(not os.path.isdir('/root/reference/deephar'), reason='needs the reference checkout')
