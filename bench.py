@@ -2,6 +2,7 @@
 """Headline benchmark of the pose-regression hot path on MI355X.
 
     python bench.py --gpus N --steps K --warmup W [--workload mpii|penn_merge|ntu_spnet]
+        (N > 1 without torch.distributed.run around it: bench.py starts the N ranks itself)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 
 Workloads (BASELINE.json `configs`):
@@ -24,7 +25,7 @@ Rank 0 prints ONE JSON line, which also carries
                  `traffic` = HBM bytes per launch from the separate rocprofv3 --pmc passes of THE SAME instantiation
                  and shape (profiles/pmc_dominant_kernel.json, written by tools/profile_round.sh), else null.
   predict_fps  : (mpii, N=1) what a caller of Model.predict gets -- host numpy arrays in, host arrays out, wall clock
-                 over 512 frames after one warm-up call (method of exp/pennaction/eval_speed2d.py:70-77), for float32
+                 over 2 048 frames after one warm-up call (method of exp/pennaction/eval_speed2d.py:70-77), for float32
                  frames and for raw uint8 frames (normalised inside the first convolution).  Never `value`.
   cpu_baseline : the CPU oracle (a port; TensorFlow/Keras are not installable here) on the host cores of this box:
                  batch 16, median of 5 after one warm-up.  N=1, rank 0 only.
@@ -253,16 +254,17 @@ def roofline(rows, kinds, total_flops_per_step, ms_per_step):
 
 
 # ---- Model.predict boundary ------------------------------------------------------------------------------------------
-def predict_boundary(model, batch, frames=512):
+def predict_boundary(model, batch, frames=2048):
     """Wall-clock frames/s of Model.predict on HOST arrays (H2D of the inputs, hipGraph replays, D2H of every output),
     one warm-up call first -- the reference's own timing method (exp/pennaction/eval_speed2d.py:70-77)."""
     rng = np.random.default_rng(7)
     res = {}
     for tag in ('f32', 'u8'):
+        reps = -(-frames // 256)              # 256 distinct frames, tiled: drawing 400 M random floats takes seconds
         if tag == 'f32':
-            x = rng.uniform(-1, 1, (frames, 256, 256, 3)).astype(np.float32)
+            x = np.tile(rng.uniform(-1, 1, (256, 256, 256, 3)).astype(np.float32), (reps, 1, 1, 1))[:frames]
         else:
-            x = rng.integers(0, 256, (frames, 256, 256, 3), dtype=np.uint8)
+            x = np.tile(rng.integers(0, 256, (256, 256, 256, 3), dtype=np.uint8), (reps, 1, 1, 1))[:frames]
         model.predict(x, batch_size=batch)      # warm-up call (binds / tunes / captures the plan, pins the staging ring)
         t0 = time.perf_counter()
         out = model.predict(x, batch_size=batch)
@@ -340,6 +342,62 @@ def timed(step, streams, steps, warmup, world, pairs=None):
     return dt
 
 
+def _free_port():
+    import socket
+    with socket.socket() as sk:
+        sk.bind(('127.0.0.1', 0))
+        return sk.getsockname()[1]
+
+
+def _spawned_rank(local_rank, world, port, argv):
+    """Entry of a rank started by `python bench.py --gpus N` itself (no torch.distributed.run around it)."""
+    os.environ.update(RANK=str(local_rank), LOCAL_RANK=str(local_rank), WORLD_SIZE=str(world),
+                      MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    sys.argv = [sys.argv[0]] + list(argv)
+    main()
+
+
+def dry_run(args, world, rank):
+    """--dry-run: the launcher, the rendezvous, the rank-major all-gather + frame re-ordering view of
+    deephar_amd/parallel.py and the one-JSON-line contract on the gloo backend, no HIP device (CPU test of the
+    `--gpus N` path; measures nothing about the product)."""
+    import torch
+    import torch.distributed as dist
+    from deephar_amd import parallel
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('gloo', rank=rank, world_size=world)
+    clips, T, J, C = 2, 4 * world, 4, 8
+    tl = T // world
+    local = torch.full((clips, tl, J, C), float(rank))
+    buf, us = None, []
+    for k in range(args.warmup + args.steps):
+        if k == args.warmup:
+            if world > 1:
+                dist.barrier()
+            t0 = time.perf_counter()
+        c0 = time.perf_counter()
+        buf = parallel.all_gather_rank_major(local, world=world, out=buf)
+        us.append(1e6 * (time.perf_counter() - c0))
+        frames = parallel.frames_view(buf).reshape(clips, T, J, C)
+        assert all(bool((frames[:, r * tl:(r + 1) * tl] == r).all()) for r in range(world))
+    if world > 1:
+        dist.barrier()
+    dt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(dt, op=dist.ReduceOp.MAX)
+    if rank == 0:
+        print(json.dumps({'metric': 'dry run of the multi-rank launcher (gloo, CPU): no product measurement',
+                          'dry_run': True, 'backend': 'gloo', 'value': round(clips * world * T * args.steps / float(dt), 1),
+                          'unit': 'frames/s', 'n_gpus': world, 'rccl_ranks': world, 'steps': args.steps,
+                          'warmup': args.warmup, 'ms_per_step': round(1e3 * float(dt) / args.steps, 3),
+                          'collective_us': round(float(np.mean(us[args.warmup:])), 2), 'higher_is_better': True,
+                          'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+                          'config': {'workload': 'launcher dry run', 'global_batch': clips * world}}))
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -365,7 +423,18 @@ def main():
     ap.add_argument('--tune-cache', default=None,
                     help='JSON file with the autotuned conv tilings: loaded if present (no tuning launches, '
                          'keeps rocprofv3 kernel stats clean), written otherwise')
+    ap.add_argument('--dry-run', action='store_true',
+                    help='launcher / rendezvous / all-gather / JSON contract on the gloo backend, no HIP device')
+    ap.add_argument('--predict-frames', type=int, default=2048,
+                    help='frames per Model.predict boundary measurement (SURVEY.md 8d: >= 2 000)')
     args = ap.parse_args()
+
+    if 'WORLD_SIZE' not in os.environ and args.gpus > 1:
+        # `python bench.py --gpus N` on its own: start the N ranks here (one process per GPU, 127.0.0.1 rendezvous on
+        # a free port); every rank re-enters main() with RANK / LOCAL_RANK / WORLD_SIZE set, rank 0 prints the line
+        import torch.multiprocessing as mp
+        mp.spawn(_spawned_rank, args=(args.gpus, _free_port(), sys.argv[1:]), nprocs=args.gpus, join=True)
+        return
 
     import torch
     import torch.distributed as dist
@@ -373,8 +442,8 @@ def main():
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
-    if world != args.gpus and world == 1 and args.gpus > 1:
-        raise SystemExit('--gpus %d needs torch.distributed.run with --nproc-per-node %d' % (args.gpus, args.gpus))
+    if args.dry_run:
+        return dry_run(args, world, rank)
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs a HIP device (the product path has no CPU fallback)')
     torch.cuda.set_device(local_rank)
@@ -501,7 +570,7 @@ def main():
                                                      spose[..., :2].max() <= 1),
                      'roofline': sroof, 'kernel_time_share': sextra['kernel_time_share']}
         if world == 1 and not args.no_predict:
-            sfps = predict_boundary(sm, per_gpu)
+            sfps = predict_boundary(sm, per_gpu, args.predict_frames)
             split_leg['predict_fps_f32'], split_leg['predict_fps_u8'] = sfps['f32'], sfps['u8']
         del sm
 
@@ -551,10 +620,11 @@ def main():
         if split_leg is not None:
             out['bf16x3'] = split_leg
         if args.workload == 'mpii' and world == 1 and not args.no_predict:
-            fps = predict_boundary(model, per_gpu)
+            fps = predict_boundary(model, per_gpu, args.predict_frames)
             out['predict_fps_f32'], out['predict_fps_u8'] = fps['f32'], fps['u8']
-            out['predict_note'] = 'Model.predict on host numpy arrays, 512 frames in batches of %d, wall clock incl. ' \
-                                  'H2D of the frames and D2H of all outputs, after one warm-up call' % per_gpu
+            out['predict_note'] = 'Model.predict on host numpy arrays, %d frames in batches of %d, wall clock incl. ' \
+                                  'H2D of the frames and D2H of all outputs, after one warm-up call' % (
+                                      args.predict_frames, per_gpu)
         if world == 1 and not args.no_cpu_baseline and args.workload == 'mpii':
             out['cpu_baseline'] = cpu_baseline(model, args.blocks)
         if args.dump_steps:

@@ -811,9 +811,13 @@ class Executor:
         return [np.concatenate([r[k] for r in results], axis=0) if len(results) > 1 else results[0][k]
                 for k in range(nres)]
 
-    def run_device(self, tensors, n=None):
+    def run_device(self, tensors, n=None, inputs_copied=None):
         """Device tensors in ([m <= n, ...] float32 on this device), device VIEWS of the outputs out (valid until the
         next forward of the same bound plan); everything is enqueued on `self.stream`, nothing touches the host.
+        An input may be any strided view with the input's element count whose leading dim is m -- e.g. the
+        [m, G, T/G, J, c] view of a rank-major all-gather result: the copy into the plan's contiguous [m, T, J, c]
+        input does the re-ordering.  `inputs_copied`: optional torch event recorded on `self.stream` right after the
+        input copies (the producer may then overwrite its buffers).
         Used by the frame-sharded clip runtime (parallel.py) around the RCCL all-gather."""
         torch = _torch()
         m = tensors[0].shape[0]
@@ -825,8 +829,14 @@ class Executor:
             if self._wstamp is None:
                 self._wstamp = self._weight_stamp()
             for v, t in zip(self.plan.inputs, tensors):
-                if tuple(t.shape[1:]) != tuple(v.shape) or m > bp.n:
+                dst = bp.tensor(v)[:m] if m <= bp.n else None
+                if dst is None or t.shape[0] != m or t.numel() != dst.numel() or \
+                        tuple(t.shape[-1:]) != tuple(v.shape[-1:]):
                     raise ValueError('input has shape %s, model expects [<=%d, %s]' % (tuple(t.shape), bp.n, v.shape))
-                bp.tensor(v)[:m].copy_(t, non_blocking=True)
+                if tuple(t.shape) != tuple(dst.shape):
+                    dst = dst.view(tuple(t.shape))
+                dst.copy_(t, non_blocking=True)
+            if inputs_copied is not None:
+                inputs_copied.record(self.stream)
             self.forward(bp)
             return [bp.tensor(v)[:m] for v in self.plan.outputs]

@@ -127,20 +127,36 @@ def split_frames(model, shards):
 # runtime
 # ---------------------------------------------------------------------------------------------------------
 
-def all_gather_frames(local, group=None, world=None):
-    """All-gather a [N, T_local, ...] tensor along the frame axis -> [N, T, ...].  Works on CUDA tensors
-    (RCCL) and CPU tensors (gloo).  One collective per call."""
+def all_gather_rank_major(local, group=None, world=None, out=None):
+    """ONE collective: all-gather a [N, T_local, ...] tensor -> [G, N, T_local, ...] (rank-major, exactly what
+    `all_gather_into_tensor` writes; no re-ordering pass).  Works on CUDA tensors (RCCL) and CPU tensors (gloo).
+    `out`: optional persistent destination of that shape.  With one rank the result is a view of `local`."""
     import torch
     import torch.distributed as dist
     world = dist.get_world_size(group) if world is None else world
     if world == 1:
-        return local
+        return local.unsqueeze(0)
     local = local.contiguous()
-    n = local.shape[0]
-    gathered = torch.empty((world * n,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
-    dist.all_gather_into_tensor(gathered, local, group=group)            # rank-major: [G * N, Tl, ...]
-    gathered = gathered.view((world, n) + tuple(local.shape[1:]))
-    return gathered.movedim(0, 1).reshape((n, world * local.shape[1]) + tuple(local.shape[2:]))
+    shape = (world,) + tuple(local.shape)
+    if out is None or tuple(out.shape) != shape or out.dtype != local.dtype or out.device != local.device:
+        out = torch.empty(shape, dtype=local.dtype, device=local.device)
+    dist.all_gather_into_tensor(out.view((world * local.shape[0],) + tuple(local.shape[1:])), local, group=group)
+    return out
+
+
+def frames_view(gathered):
+    """[G, N, Tl, ...] -> the strided VIEW [N, G, Tl, ...]; flattening (G, Tl) gives the clip's frame axis in order.
+    A consumer that copies it into its own contiguous [N, T, ...] input (Executor.run_device) does the re-ordering
+    inside a copy it makes anyway."""
+    return gathered.permute((1, 0) + tuple(range(2, gathered.dim())))
+
+
+def all_gather_frames(local, group=None, world=None):
+    """All-gather a [N, T_local, ...] tensor along the frame axis -> contiguous [N, T, ...] (one collective + one
+    re-ordering copy; the device-resident runtime below avoids the copy, this form serves host-side callers)."""
+    g = all_gather_rank_major(local, group, world)
+    n, tl = local.shape[0], local.shape[1]
+    return frames_view(g).reshape((n, g.shape[0] * tl) + tuple(local.shape[2:]))
 
 
 class ShardedClipModel:
@@ -148,8 +164,15 @@ class ShardedClipModel:
 
     Default (HIP) path, device resident end to end: this rank's frames [N, T/G, H, W, C] (host array or device tensor)
     -> frame stage (hipGraph replay, `Executor.run_device`) -> packed device view [N, T/G, J, Cp] -> ONE all-gather
-    (RCCL over xGMI) -> the head stage's inputs are channel slices of the gathered tensor, copied device-to-device into
-    its plan -> head stage (hipGraph replay) -> device views of the outputs; only `predict` copies results to the host.
+    (RCCL over xGMI) into a persistent [G, N, T/G, J, Cp] buffer -> the head stage's inputs are strided channel
+    slices of that buffer, re-ordered to [N, T, J, c] by the device-to-device copy into the head's plan (no separate
+    re-ordering pass) -> head stage (hipGraph replay) -> device views of the outputs; only `predict` copies results
+    to the host.
+
+    Streams: the frame stage runs on its executor's stream F, the collective on torch's current stream C, the head
+    stage on its executor's stream H.  Per step: F waits for C (the caller's input, and the previous collective's
+    read of the frame arena) and for the event E recorded after H's input copies of the previous step (with one rank
+    H reads the frame arena directly); C waits for F and for E (the gather buffer is re-used); H waits for C.
 
     frame_fn(x_local [N, T/G, H, W, C]) -> packed [N, T/G, J, Cp] (torch tensor, any device)
     head_fn(list of [N, T, J, c_i])     -> list of arrays / tensors
@@ -172,47 +195,62 @@ class ShardedClipModel:
         self.frame_fn = frame_fn or self._frame_hip
         self.head_fn = head_fn or self._head_hip
         self.last_outputs = None
+        self._gather_buf = None
+        self._head_inputs_read = None        # event: the head stage's input copies of the previous step are done
 
     # -- default stages on the GPU -----------------------------------------------------------------------
     def _frame_hip(self, x_local):
         import torch
         ex = self.frame_model.executor
+        cur = torch.cuda.current_stream()
+        ex.stream.wait_stream(cur)           # x_local may come from C; C also read the frame arena (last collective)
+        if self._head_inputs_read is not None:
+            ex.stream.wait_event(self._head_inputs_read)
+            cur.wait_event(self._head_inputs_read)          # ... and the gather buffer is about to be overwritten
         if isinstance(x_local, np.ndarray):
             x_local = torch.from_numpy(np.ascontiguousarray(x_local, dtype=np.float32)).to(ex.device)
         out = ex.run_device([x_local])[0]                       # device view of the packed tensor, on ex.stream
-        torch.cuda.current_stream().wait_stream(ex.stream)      # the collective runs behind torch's current stream
+        cur.wait_stream(ex.stream)                              # the collective runs behind torch's current stream
         return out
 
     def _head_hip(self, tensors):
         import torch
         ex = self.head_model.executor
         ex.stream.wait_stream(torch.cuda.current_stream())      # ... and the head stage behind the collective
-        return ex.run_device(tensors)
+        if self._head_inputs_read is None:
+            self._head_inputs_read = torch.cuda.Event()
+        return ex.run_device(tensors, inputs_copied=self._head_inputs_read)
 
     def forward_device(self, x_local, events=None):
         """One clip batch, nothing leaves the device.  `events` = (start, stop) torch events recorded around the
-        collective on the current stream (bench.py: collective_us).  Returns the outputs in model order."""
+        collective on the current stream (bench.py: collective_us).  Returns the outputs in model order (pose
+        tensors that pass straight through the cut are small contiguous copies, made after the head was enqueued)."""
         info = self.info
         packed = self.frame_fn(x_local)
         if events is not None:
             events[0].record()
-        full = all_gather_frames(packed, self.group, self.world)             # [N, T, J, Cp]
+        gathered = all_gather_rank_major(packed, self.group, self.world, out=self._gather_buf)   # [G, N, Tl, J, Cp]
+        if self.world > 1:
+            self._gather_buf = gathered
         if events is not None:
             events[1].record()
+        full = frames_view(gathered)                                                            # [N, G, Tl, J, Cp]
+        n, t = full.shape[0], full.shape[1] * full.shape[2]
         parts = [full[..., off:off + c] for (_, off, c) in info['cut']]
+        flat = lambda v: v.reshape((n, t) + tuple(v.shape[3:]))
         outs = [None] * len(self.model.outputs)
-        for k, ci in info['passthrough'].items():
-            outs[k] = parts[ci]
         if self.head_model is not None:
-            head = self.head_fn(parts)
+            hip_head = getattr(self.head_fn, '__func__', None) is ShardedClipModel._head_hip
+            head = self.head_fn(parts if hip_head else [flat(p) for p in parts])
             for k, o in zip(info['head_outputs'], head):
                 outs[k] = o
+        for k, ci in info['passthrough'].items():
+            outs[k] = flat(parts[ci])
         self.last_outputs = outs
         return outs
 
     def predict(self, clips):
         """clips: [N, T, H, W, C] (the same array on every rank).  Returns the model's outputs (host arrays)."""
-        import torch
         info = self.info
         lo = self.rank * info['Tl']
         outs = self.forward_device(np.ascontiguousarray(clips[:, lo:lo + info['Tl']]))
