@@ -151,8 +151,6 @@ def cpu_baseline(model, blocks):
 def kernel_name(s):
     """The template instantiation a conv step launches, spelled as rocprofv3 demangles it."""
     cfg = s.attrs.get('tile_cfg', -1)
-    if s.kind == 'sepconv':
-        return 'sepconv_fused_kernel (tiling %d)' % cfg
     if s.attrs.get('split_k'):
         return 'conv_splitk_kernel'
     if cfg < 0:
@@ -165,9 +163,6 @@ def kernel_name(s):
             return 'gemm1x1s_wide_kernel<%d, %s, %s, %s>' % (SPLIT_WIDE[cfg], b(a['up2']), b(a['pre_relu']), b(kxk))
         t, ns = SPLIT_TILES[cfg]
         return 'gemm1x1s_kernel<%d, %d, %d, %d, %s, %s, %s, %d>' % (t + (b(a['up2']), b(a['pre_relu']), b(kxk), ns))
-    if cfg >= 18:
-        kxk = not (a['kh'] == a['kw'] == 1 and a['sh'] == a['sw'] == 1 and a['pt'] == a['pl'] == 0)
-        return 'gemm1x1_wide_kernel<%d, %s, %s, %s>' % ({18: 4, 19: 2}[cfg], b(a['up2']), b(a['pre_relu']), b(kxk))
     t = TILES[cfg % 9]
     if cfg >= 9:
         kxk = not (a['kh'] == a['kw'] == 1 and a['sh'] == a['sw'] == 1 and a['pt'] == a['pl'] == 0)
@@ -194,13 +189,13 @@ def profile_plans(bound):
 
 
 def roofline(rows, kinds, total_flops_per_step, ms_per_step):
-    conv_kinds = [k for k in ('conv', 'sepconv') if k in kinds]
+    conv_kinds = [k for k in ('conv',) if k in kinds]
     conv = dict(ms=sum(kinds[k]['ms'] for k in conv_kinds), flops=sum(kinds[k]['flops'] for k in conv_kinds),
                 launches=sum(kinds[k]['launches'] for k in conv_kinds))
     eager_total_ms = sum(ms for _, ms, _ in rows)
     by_kernel = {}
     for s, ms, n in rows:
-        if s.kind not in ('conv', 'sepconv'):
+        if s.kind != 'conv':
             continue
         g = by_kernel.setdefault(kernel_name(s), dict(ms=0.0, flops=0.0, launches=0, shapes={}))
         g['ms'] += ms
@@ -628,7 +623,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline and args.workload == 'mpii':
             out['cpu_baseline'] = cpu_baseline(model, args.blocks)
         if args.dump_steps:
-            dump = [dict(kind=s.kind, name=s.name, kernel=kernel_name(s) if s.kind in ('conv', 'sepconv') else s.kind,
+            dump = [dict(kind=s.kind, name=s.name, kernel=kernel_name(s) if s.kind == 'conv' else s.kind,
                          ms=ms, gflop=s.flops(n) / 1e9, mbytes=s.bytes(n) / 1e6,
                          out=list(next(iter(s.outs.values())).shape) if s.outs else None) for s, ms, n in rows]
             with open(args.dump_steps, 'w') as f:

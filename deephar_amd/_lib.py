@@ -18,11 +18,7 @@ class ConvArgs(C.Structure):
                                    'res1', 'res2', 'in_lut')] + \
                [(n, i32) for n in ('N', 'H', 'W', 'Cin', 'ldx', 'OH', 'OW', 'Cout', 'ldy', 'KH', 'KW', 'SH',
                                    'SW', 'PT', 'PL', 'K', 'Kp', 'Np', 'ldr1', 'ldr2', 'pre_relu', 'post_relu',
-                                   'up2', 'x_u8', 'w_split', 'ldyp')] + [('y_pool', vp)]
-
-
-class SepConvArgs(C.Structure):
-    _fields_ = [('pw', ConvArgs), ('dw_w', vp)] + [(n, i32) for n in ('DKH', 'DKW', 'DPT', 'DPL')]
+                                   'up2', 'x_u8', 'w_split')]
 
 
 class DwArgs(C.Structure):
@@ -60,9 +56,8 @@ SIGNATURES = {
     'dh_conv2d_num_split_tile_cfgs': (C.c_int, []),
     'dh_conv2d_pick_tile_cfg': (C.c_int, [C.c_int, C.c_int]),
     'dh_conv2d_uses_split_k': (C.c_int, [C.POINTER(ConvArgs)]),
+    'dh_conv2d_split_eligible': (C.c_int, [C.POINTER(ConvArgs)]),
     'dh_conv2d_f32': (C.c_int, [C.POINTER(ConvArgs), C.c_int, vp]),
-    'dh_sepconv2d_num_tile_cfgs': (C.c_int, []),
-    'dh_sepconv2d_f32': (C.c_int, [C.POINTER(SepConvArgs), C.c_int, vp]),
     'dh_normalize_u8_f32': (C.c_int, [vp, vp, vp, C.c_int64, C.c_int, vp]),
     'dh_dwconv2d_f32': (C.c_int, [C.POINTER(DwArgs), vp]),
     'dh_pool2d_f32': (C.c_int, [C.POINTER(PoolArgs), vp]),

@@ -97,6 +97,7 @@ int dh_conv2d_num_tile_cfgs(void) { return conv_igemm_num_cfgs(); }
 int dh_conv2d_num_split_tile_cfgs(void) { return gemm1x1_split_num_cfgs(); }
 int dh_conv2d_uses_split_k(const dh_conv_args* a) { return a != nullptr && conv_is_skinny(*a) ? 1 : 0; }
 int dh_conv2d_pick_tile_cfg(int M, int Cout) { return conv_igemm_pick_cfg(M, Cout); }
+int dh_conv2d_split_eligible(const dh_conv_args* a) { return a != nullptr && gemm1x1_split_eligible(*a) ? 1 : 0; }
 
 int dh_conv2d_f32(const dh_conv_args* a, int tile_cfg, void* stream) {
   if (a == nullptr || a->x == nullptr || a->w == nullptr || a->y == nullptr) return DH_EINVAL;
@@ -115,17 +116,6 @@ int dh_dwconv2d_f32(const dh_dw_args* a, void* stream) {
   if (a == nullptr || a->x == nullptr || a->w == nullptr || a->y == nullptr) return DH_EINVAL;
   if ((a->pre_scale == nullptr) != (a->pre_shift == nullptr)) return DH_EINVAL;
   return launch_dwconv(*a, S(stream));
-}
-
-int dh_sepconv2d_num_tile_cfgs(void) { return sepconv_num_cfgs(); }
-
-int dh_sepconv2d_f32(const dh_sepconv_args* a, int tile_cfg, void* stream) {
-  if (a == nullptr || a->pw.x == nullptr || a->pw.w == nullptr || a->pw.y == nullptr || a->dw_w == nullptr)
-    return DH_EINVAL;
-  if ((a->pw.post_scale == nullptr) != (a->pw.post_shift == nullptr)) return DH_EINVAL;
-  if (a->pw.Kp % 32 != 0 || a->pw.Np % 32 != 0 || a->pw.Kp < a->pw.K || a->pw.Np < a->pw.Cout) return DH_EINVAL;
-  if (tile_cfg >= sepconv_num_cfgs()) return DH_EINVAL;
-  return launch_sepconv_fused(a->pw, a->dw_w, a->DKH, a->DKW, a->DPT, a->DPL, tile_cfg, S(stream));
 }
 
 int dh_pool2d_f32(const dh_pool_args* a, void* stream) {

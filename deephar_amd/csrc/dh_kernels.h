@@ -19,10 +19,8 @@ int conv_igemm_pick_cfg(int M, int Cout);
 int conv_igemm_num_cfgs();
 bool conv_is_skinny(const ConvArgs& a);
 int gemm1x1_split_num_cfgs();
+bool gemm1x1_split_eligible(const ConvArgs& a);
 int launch_dwconv(const DwArgs& a, hipStream_t s);
-int sepconv_num_cfgs();
-int launch_sepconv_fused(const ConvArgs& pw, const float* dw, int dkh, int dkw, int dpt, int dpl, int cfg,
-                         hipStream_t s);
 int launch_pool(const PoolArgs& a, hipStream_t s);
 int launch_upsample2x_add(const float* a, int lda, const float* b, int ldb, float* y, int ldy, int N, int H,
                           int W, int C, hipStream_t s);

@@ -271,198 +271,6 @@ int launch_variant(const ConvArgs& a, int epi, unsigned tiles, hipStream_t s) {
   return check_launch();
 }
 
-// ---------------------------------------------------------------------------------------------------------------
-// Wide per-wave tile: 32 rows x 192 columns per wave, WM waves stacked over M (work-group tile 32 WM x 192), 16-k
-// K-steps, two LDS stages of 20 KB.  Beside an fp32 MFMA nothing issues for free, so the K loop's efficiency is
-// MFMA cycles / (MFMA cycles + issue cycles of everything else), and what is left beside the MFMAs in this kernel is
-// LDS-DMA pieces (~60 cycles each) and fragment reads (~8 each).  Per MFMA the 128 x 64 tiling issues 0.19 pieces and
-// 0.38 reads, this one 0.10 and 0.29 (the A rows are read once for six column tiles instead of two).
-// K order per accumulator, fragment mapping and epilogue are those of gemm1x1_kernel: results are bit-identical.
-template <int WM, bool UP2, bool RELU, bool KXK>
-__global__ __launch_bounds__(WM * 64, 2) void gemm1x1_wide_kernel(const ConvArgs p, const int epi_vec) {
-  constexpr int NT = WM * 64;
-  constexpr int BKW = 16;
-  constexpr int BM = WM * 32, BN = 192;
-  constexpr int APASS = BM * 4 / NT;                      // 16-byte units of the A stage per thread (= 2)
-  constexpr int BROWS = 4 * BN;                          // 16-byte units of the B stage: 4 k-groups x BN
-  constexpr int BPASS = BROWS / NT;
-  constexpr int A_BYTES = BM * BKW * 4;
-  constexpr int STAGE_BYTES = A_BYTES + BROWS * 16;
-  static_assert(BROWS % NT == 0, "tile/thread mismatch");
-  static_assert(STAGE_BYTES + 3 * BN * 16 + 5 * 512 < 65536, "ds_read immediate offsets");
-
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = tid >> 6;
-  const int li = lane & 31, lh = lane >> 5;
-  const int M = p.N * p.OH * p.OW;
-  const int tiles_n = (p.Cout + BN - 1) / BN;
-  const int tile = xcd_tile(blockIdx.x, gridDim.x);
-  const int m0 = (tile / tiles_n) * BM;
-  const int n0 = (tile % tiles_n) * BN;
-
-  const int wave_u = __builtin_amdgcn_readfirstlane(wave);
-  const auto rs_x = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<float*>(p.x), 0, (int)(((unsigned)(p.N * p.H * p.W - 1) * p.ldx + (unsigned)p.Cin) * 4u), 0x00020000);
-  const auto rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.w), 0, (int)((unsigned)p.Kp * p.Np * 4u),
-                                                      0x00020000);
-  // A stage: 64-byte rows of four 16-byte slots, slot XOR ((row >> 2) & 3): the 16 lanes ds_read_b128 serves per cycle
-  // (rows {0-3, 12-15, 20-27} / {4-11, 16-19, 28-31} of a wave's block) then fall on 16 different bank groups
-  unsigned a_off[APASS];
-  int a_slot[APASS];
-  int a_pix[KXK ? APASS : 1], a_ih0[KXK ? APASS : 1], a_iw0[KXK ? APASS : 1];
-#pragma unroll
-  for (int ps = 0; ps < APASS; ++ps) {
-    const int r = (tid >> 2) + ps * (NT / 4);
-    int m = m0 + r;
-    m = m < M ? m : M - 1;
-    a_slot[ps] = ((tid & 3) ^ ((r >> 2) & 3)) * 4;
-    if constexpr (KXK) {
-      const int n = m / (p.OH * p.OW);
-      const int rem = m - n * (p.OH * p.OW);
-      const int oh = rem / p.OW, ow = rem - oh * p.OW;
-      a_pix[ps] = n * p.H * p.W;
-      a_ih0[ps] = oh * p.SH - p.PT;
-      a_iw0[ps] = ow * p.SW - p.PL;
-      a_off[ps] = 0;
-    } else {
-      a_off[ps] = ((unsigned)m * p.ldx + a_slot[ps]) * 4u;
-    }
-  }
-  const int chunks_per_tap = KXK ? p.Cin / BKW : 1;
-  unsigned b_off[BPASS];
-#pragma unroll
-  for (int q = 0; q < BPASS; ++q) {
-    const int idx = tid + q * NT;
-    const int kq = idx / BN, j = idx - kq * BN;
-    b_off[q] = n0 + j < p.Np ? ((unsigned)kq * p.Np + n0 + j) * 16u : OOB;
-  }
-  const int b_step = 4 * p.Np * 16;                       // bytes per 16-k K-step in the packed weight
-
-  auto issue = [&](int kt, int stage) {
-    float* sA = smem + stage * (STAGE_BYTES / 4);
-    float* sB = sA + A_BYTES / 4;
-    int kh = 0, kw = 0, c0 = 0;
-    if constexpr (KXK) {
-      const int tap = kt / chunks_per_tap;
-      c0 = (kt - tap * chunks_per_tap) * BKW;
-      kh = tap / p.KW;
-      kw = tap - kh * p.KW;
-    }
-#pragma unroll
-    for (int ps = 0; ps < APASS; ++ps) {
-      if constexpr (KXK) {
-        const int ih = a_ih0[ps] + kh, iw = a_iw0[ps] + kw;
-        const bool ok = (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W && kt * BKW < p.K;
-        const unsigned off = ok ? ((unsigned)(a_pix[ps] + ih * p.W + iw) * p.ldx + c0 + a_slot[ps]) * 4u : OOB;
-        dma16(rs_x, sA + (ps * NT + wave_u * 64) * 4, off, 0);
-      } else {
-        dma16(rs_x, sA + (ps * NT + wave_u * 64) * 4, a_off[ps], kt * BKW * 4);
-      }
-    }
-#pragma unroll
-    for (int q = 0; q < BPASS; ++q) dma16(rs_w, sB + (q * NT + wave_u * 64) * 4, b_off[q], kt * b_step);
-  };
-
-  f32x16 acc[2][1][3];                                    // [column slice][1][column tile of the slice]
-#pragma unroll
-  for (int h = 0; h < 2; ++h)
-#pragma unroll
-    for (int j = 0; j < 3; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[h][0][j][r] = 0.f;
-
-  const int nk = p.Kp / BKW;                              // even, >= 2 (Kp is a multiple of 32)
-  issue(0, 0);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-
-  const unsigned lds0 = (unsigned)(uintptr_t)(lptr_t)smem;
-  const unsigned sw = (unsigned)((li >> 2) & 3);
-  const unsigned a_rd0 = lds0 + (unsigned)((wave * 32 + li) * 64) + (((0u + lh) ^ sw) << 4);     // k-group lh
-  const unsigned a_rd1 = lds0 + (unsigned)((wave * 32 + li) * 64) + (((2u + lh) ^ sw) << 4);     // k-group 2 + lh
-  const unsigned b_rd = lds0 + (unsigned)A_BYTES + (unsigned)((lh * BN + li) * 16);
-
-  // sub-step S of stage ST: A fragment = k-group 2S + lh of the wave's rows, B fragments = the same k-group of the six
-  // column tiles; stage, sub-step and column tile are compile-time (one base register + immediate per ds_read)
-#define DH_FETCH(FA, FB, ST, S)                                                                           \
-  FA = lds_rd<(ST) * STAGE_BYTES>((S) ? a_rd1 : a_rd0);                                                   \
-  FB[0] = lds_rd<(ST) * STAGE_BYTES + (S) * 2 * BN * 16 + 0 * 512>(b_rd);                                 \
-  FB[1] = lds_rd<(ST) * STAGE_BYTES + (S) * 2 * BN * 16 + 1 * 512>(b_rd);                                 \
-  FB[2] = lds_rd<(ST) * STAGE_BYTES + (S) * 2 * BN * 16 + 2 * 512>(b_rd);                                 \
-  FB[3] = lds_rd<(ST) * STAGE_BYTES + (S) * 2 * BN * 16 + 3 * 512>(b_rd);                                 \
-  FB[4] = lds_rd<(ST) * STAGE_BYTES + (S) * 2 * BN * 16 + 4 * 512>(b_rd);                                 \
-  FB[5] = lds_rd<(ST) * STAGE_BYTES + (S) * 2 * BN * 16 + 5 * 512>(b_rd);
-  auto mfma_block = [&](float4 a, const float4 (&b)[6]) {
-    if constexpr (RELU) a = relu4(a);
-#pragma unroll
-    for (int j = 0; j < 6; ++j) {
-      f32x16& c = acc[j / 3][0][j % 3];
-      c = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b[j].x, c, 0, 0, 0);
-      c = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b[j].y, c, 0, 0, 0);
-      c = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b[j].z, c, 0, 0, 0);
-      c = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b[j].w, c, 0, 0, 0);
-    }
-  };
-  EpiPrefetch<1, 3> pre0;
-  // one K-step on stage ST: the first fragment read has no MFMAs to hide behind, the next K-step's DMA goes there
-#define DH_KSTEP(ST)                                                                                      \
-  {                                                                                                       \
-    float4 fa0, fa1, fb0[6], fb1[6];                                                                      \
-    if (kt == nk - 1) pre0.template issue<WM, 1>(p, m0, n0, M, epi_vec);                                  \
-    DH_FETCH(fa0, fb0, ST, 0)                                                                             \
-    __builtin_amdgcn_sched_barrier(0);                                                                    \
-    if (kt + 1 < nk) issue(kt + 1, 1 - (ST));                                                             \
-    lgkm_wait();                                                                                          \
-    DH_FETCH(fa1, fb1, ST, 1)                                                                             \
-    __builtin_amdgcn_sched_barrier(0);                                                                    \
-    mfma_block(fa0, fb0);                                                                                 \
-    lgkm_wait();                                                                                          \
-    mfma_block(fa1, fb1);                                                                                 \
-    __builtin_amdgcn_sched_barrier(0);   /* the whole block is the DMA's cover: no MFMA behind the wait */ \
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                      \
-    __syncthreads();                                                                                      \
-  }
-  for (int kt = 0; kt < nk; ++kt) {
-    DH_KSTEP(0)
-    ++kt;
-    DH_KSTEP(1)
-  }
-#undef DH_KSTEP
-#undef DH_FETCH
-
-  // columns 0-95 (residual rows requested during the last K-step), then 96-191 through the same slab
-  conv_epilogue<WM, 1, 1, 3, UP2, true>(p, acc[0], smem, m0, n0, M, epi_vec, pre0);
-  conv_epilogue<WM, 1, 1, 3, UP2, false>(p, acc[1], smem, m0, n0 + 96, M, epi_vec, pre0);
-}
-
-template <int WM, bool UP2, bool RELU, bool KXK>
-int launch_wide_variant(const ConvArgs& a, int epi, unsigned tiles, hipStream_t s) {
-  constexpr int kStage = 2 * (WM * 32 * 16 * 4 + 4 * 192 * 16), kEpi = WM * 32 * (3 * 32 + 4) * 4;
-  constexpr size_t lds = kStage > kEpi ? kStage : kEpi;
-  auto kern = gemm1x1_wide_kernel<WM, UP2, RELU, KXK>;
-  hipLaunchKernelGGL(kern, dim3(tiles), dim3(WM * 64), lds, s, a, epi);
-  return check_launch();
-}
-
-template <int WM>
-int launch_wide(const ConvArgs& a, int epi, hipStream_t s) {
-  constexpr int BM = WM * 32, BN = 192;
-  const long long M = (long long)a.N * a.OH * a.OW;
-  const long long tiles = ((M + BM - 1) / BM) * ((a.Cout + BN - 1) / BN);
-  if (tiles <= 0 || tiles > 0x7fffffffLL) return DH_EINVAL;
-  const unsigned t = (unsigned)tiles;
-  if (a.up2)
-    return a.pre_relu ? launch_wide_variant<WM, true, true, false>(a, epi, t, s)
-                      : launch_wide_variant<WM, true, false, false>(a, epi, t, s);
-  if (!(a.KH == 1 && a.KW == 1 && a.SH == 1 && a.SW == 1 && a.PT == 0 && a.PL == 0))
-    return a.pre_relu ? launch_wide_variant<WM, false, true, true>(a, epi, t, s)
-                      : launch_wide_variant<WM, false, false, true>(a, epi, t, s);
-  return a.pre_relu ? launch_wide_variant<WM, false, true, false>(a, epi, t, s)
-                    : launch_wide_variant<WM, false, false, false>(a, epi, t, s);
-}
-
 template <int WM, int WN, int TM, int TN>
 int launch_cfg(const ConvArgs& a, int epi, hipStream_t s) {
   constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
@@ -470,7 +278,6 @@ int launch_cfg(const ConvArgs& a, int epi, hipStream_t s) {
   const long long tiles = ((M + BM - 1) / BM) * ((a.Cout + BN - 1) / BN);
   if (tiles <= 0 || tiles > 0x7fffffffLL) return DH_EINVAL;
   const unsigned t = (unsigned)tiles;
-  if (a.y_pool != nullptr && !conv_epilogue_pools<WM, TM, false>()) return DH_EUNSUPPORTED;
   if (a.up2) {
     if constexpr (TM * TN >= 6) {
       return DH_EUNSUPPORTED;
@@ -512,12 +319,10 @@ int launch_gemm1x1(const ConvArgs& a, int cfg, int epi, hipStream_t s) {
     case 6: return launch_cfg<2, 1, 1, 2>(a, epi, s);
     case 7: return launch_cfg<2, 1, 1, 1>(a, epi, s);
     case 8: return launch_cfg<1, 1, 1, 1>(a, epi, s);
-    case 9: return launch_wide<4>(a, epi, s);      // 128 x 192, four waves of 32 x 192, 16-k K-steps
-    case 10: return launch_wide<2>(a, epi, s);     // 64 x 192
   }
   return DH_EINVAL;
 }
 
-int gemm1x1_num_cfgs() { return 11; }
+int gemm1x1_num_cfgs() { return 9; }
 
 }  // namespace dh

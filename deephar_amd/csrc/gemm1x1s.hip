@@ -30,7 +30,7 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 // buffer_load_dwordx4 ... offen lds: 16 bytes per lane from (descriptor base + voff + soff) to LDS (wave-uniform `dst`
 // + lane * 16).  A 32-bit per-lane offset fixed over K plus a SCALAR K-step offset: no per-step 64-bit address VALU
 // (5.7 VALU per MFMA were measured in the first version of this kernel; about 4 hide under a bf16 MFMA).  An
-// out-of-range offset loads zeros.  The builtin only exists for the gfx950 pass (see sepconv_fused.hip).
+// out-of-range offset loads zeros.  The builtin only exists for the gfx950 pass (see gemm1x1.hip dma16).
 template <typename RSRC>
 __device__ __forceinline__ void dma16(RSRC rs, float* dst, unsigned voff, int soff) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -686,7 +686,6 @@ int launch_cfg(const ConvArgs& a, int epi, hipStream_t s) {
   const long long tiles = ((M + BM - 1) / BM) * ((a.Cout + BN - 1) / BN);
   if (tiles <= 0 || tiles > 0x7fffffffLL) return DH_EINVAL;
   const unsigned t = (unsigned)tiles;
-  if (a.y_pool != nullptr && !conv_epilogue_pools<WM, TM, false>()) return DH_EUNSUPPORTED;
   if (a.up2) {
     if constexpr (TM * TN >= 6) {
       return DH_EUNSUPPORTED;
@@ -706,11 +705,18 @@ int launch_cfg(const ConvArgs& a, int epi, hipStream_t s) {
 
 bool gemm1x1_eligible(const ConvArgs& a);
 
-int launch_gemm1x1_split(const ConvArgs& a, int cfg, int epi, hipStream_t s) {
-  if (!gemm1x1_eligible(a)) return DH_EUNSUPPORTED;
+// What dh_conv2d_f32 accepts with w_split = 1 (the weight pointer itself is not looked at: a binding asks before it packs).
+bool gemm1x1_split_eligible(const ConvArgs& a0) {
+  ConvArgs a = a0;
+  a.w = reinterpret_cast<const float*>(uintptr_t(16));
+  a.w_split = 0;                       // (conv_is_skinny answers for the fp32 packing)
+  if (a.x_u8 || conv_is_skinny(a) || !gemm1x1_eligible(a)) return false;
   // 32-bit byte offsets into the buffer descriptors
-  if ((long long)a.N * a.H * a.W * a.ldx * 4 > 0xf0000000LL || (long long)a.Kp * a.Np * 6 > 0xf0000000LL)
-    return DH_EUNSUPPORTED;
+  return (long long)a.N * a.H * a.W * a.ldx * 4 <= 0xf0000000LL && (long long)a.Kp * a.Np * 6 <= 0xf0000000LL;
+}
+
+int launch_gemm1x1_split(const ConvArgs& a, int cfg, int epi, hipStream_t s) {
+  if (!gemm1x1_eligible(a) || !gemm1x1_split_eligible(a)) return DH_EUNSUPPORTED;
   switch (cfg) {
     case 0: return launch_cfg<2, 2, 2, 3>(a, epi, s);
     case 1: return launch_cfg<2, 2, 2, 2>(a, epi, s);

@@ -180,27 +180,14 @@ class BoundPlan:
         for step in plan.steps:
             self._bind(step)
 
-    def split_ok(self, s):
-        """Does this conv step run on the bf16 matrix cores (plan.gemm_precision == 'bf16x3')?  Mirrors gemm1x1_eligible
-        (gemm1x1.hip): LDS-DMA GEMM shapes only -- pointwise, or K x K with Cin % 32 == 0 and no fused up-sampling;
-        16-byte aligned input view; no BatchNorm prologue; float input."""
-        if getattr(self.plan, 'gemm_precision', 'f32') != 'bf16x3' or 'pre_bn' in s.params:
+    def split_ok(self, args):
+        """Does this conv step run on the bf16 matrix cores (plan.gemm_precision == 'bf16x3')?  The LIBRARY decides
+        (dh_conv2d_split_eligible: LDS-DMA GEMM shapes, aligned float input, no BN prologue, not a split-K layer, 32-bit
+        offset limits), asked with the launch's own argument struct before the weights are packed -- a layer is never
+        bound with a packing its launch would reject."""
+        if getattr(self.plan, 'gemm_precision', 'f32') != 'bf16x3':
             return False
-        a, x = s.attrs, s.ins['x']
-        if x.ld % 4 or x.coff % 4:
-            return False
-        if self.u8 is not None and id(x.buf) in self.u8 and self.u8[id(x.buf)][2]:
-            return False
-        y = s.outs['y']
-        up = 2 if a['up2'] else 1
-        # tiny per-frame output + long reduction: the split-K kernel, which reads fp32-packed weights
-        if split_k_rule((y.shape[-3] // up) * (y.shape[-2] // up), a['kh'] * a['kw'] * a['Cin'], y.C, a['Cin']):
-            return False
-        same = x.shape[-3] == y.shape[-3] // up and x.shape[-2] == y.shape[-2] // up
-        pointwise = a['kh'] == a['kw'] == 1 and a['sh'] == a['sw'] == 1 and a['pt'] == a['pl'] == 0 and same and \
-            a['Cin'] % 4 == 0
-        kxk = a['Cin'] % 32 == 0 and not a['up2']
-        return pointwise or kxk
+        return bool(self.lib.dh_conv2d_split_eligible(C.byref(args)))
 
     # ---- views -------------------------------------------------------------------------------------------
     def ptr(self, v):
@@ -228,13 +215,10 @@ class BoundPlan:
             v = d.get(role)
             return P(v) if v is not None else None
 
-        if k in ('conv', 'sepconv'):
+        if k == 'conv':
             x, y = s.ins['x'], s.outs['y']
-            split = k == 'conv' and self.split_ok(s)
-            wt, kp, np_ = self.store.conv_weight(s.params['w'], split=split)
-            sep = _lib.SepConvArgs() if k == 'sepconv' else None
-            args = sep.pw if sep is not None else _lib.ConvArgs()
-            args.x, args.w, args.y = P(x), wt.data_ptr(), P(y)
+            args = _lib.ConvArgs()
+            args.x, args.y = P(x), P(y)
             if 'pre_bn' in s.params:
                 sc, sh = self.store.bn_affine(s.params['pre_bn'])
                 args.pre_scale, args.pre_shift = sc.data_ptr(), sh.data_ptr()
@@ -246,29 +230,25 @@ class BoundPlan:
             args.H, args.W, args.Cin, args.ldx = x.shape[-3], x.shape[-2], x.C, x.ld
             args.OH, args.OW, args.Cout, args.ldy = y.shape[-3] // up, y.shape[-2] // up, a['Cout'], y.ld
             args.KH, args.KW, args.SH, args.SW, args.PT, args.PL = a['kh'], a['kw'], a['sh'], a['sw'], a['pt'], a['pl']
-            args.K, args.Kp, args.Np = a['K'], kp, np_
+            kp_np = (C.c_int(), C.c_int())
+            _lib.check(lib.dh_conv2d_packed_dims(a['kh'], a['kw'], x.C, a['Cout'], C.byref(kp_np[0]), C.byref(kp_np[1])))
+            args.K, args.Kp, args.Np = a['K'], kp_np[0].value, kp_np[1].value
             r1, r2 = s.ins.get('res1'), s.ins.get('res2')
             if r1 is not None:
                 args.res1, args.ldr1 = P(r1), r1.ld
             if r2 is not None:
                 args.res2, args.ldr2 = P(r2), r2.ld
             args.pre_relu, args.post_relu, args.up2 = a['pre_relu'], a['post_relu'], a['up2']
-            args.w_split = int(split)
-            a['w_split'] = int(split)                  # (read by bench.py to name the kernel)
-            yp = s.outs.get('ypool')
-            if yp is not None:                         # planner rule R7: the 2x2 max-pooled second output
-                args.y_pool, args.ldyp = P(yp), yp.ld
             if self.u8 is not None and id(x.buf) in self.u8 and self.u8[id(x.buf)][2]:
                 buf, lut, _ = self.u8[id(x.buf)]
                 args.x, args.in_lut, args.x_u8 = buf.data_ptr(), lut.data_ptr(), 1
-            if sep is not None:
-                sep.dw_w = self.store.dw_weight(s.params['dw']).data_ptr()
-                sep.DKH, sep.DKW, sep.DPT, sep.DPL = a['dkh'], a['dkw'], a['dpt'], a['dpl']
-                self._keep.append(sep)
-                self.calls.append((lib.dh_sepconv2d_f32, (C.byref(sep), a.get('tile_cfg', -1)), s))
-            else:
-                self._keep.append(args)
-                self.calls.append((lib.dh_conv2d_f32, (C.byref(args), a.get('tile_cfg', -1)), s))
+            split = self.split_ok(args)                # every field but w / w_split is final here
+            wt, kp, np_ = self.store.conv_weight(s.params['w'], split=split)
+            assert (kp, np_) == (args.Kp, args.Np)
+            args.w, args.w_split = wt.data_ptr(), int(split)
+            a['w_split'] = int(split)                  # (read by bench.py to name the kernel)
+            self._keep.append(args)
+            self.calls.append((lib.dh_conv2d_f32, (C.byref(args), a.get('tile_cfg', -1)), s))
         elif k == 'dwconv':
             x, y = s.ins['x'], s.outs['y']
             args = _lib.DwArgs()
@@ -475,8 +455,7 @@ class BoundPlan:
                  r1.ld % 4 if r1 is not None else 0, r2.ld % 4 if r2 is not None else 0)
         return (x.lead(3), x.shape[-3], x.shape[-2], x.C, x.ld, y.ld, a['Cout'], a['kh'], a['kw'], a['sh'],
                 a['sw'], a['pre_relu'], a['post_relu'], a['up2'], 'res1' in step.ins, 'res2' in step.ins,
-                'pre_bn' in step.params, 'post_bn' in step.params, a['pt'], a['pl'], y.shape[-3], y.shape[-2],
-                'ypool' in step.outs) + align
+                'pre_bn' in step.params, 'post_bn' in step.params, a['pt'], a['pl'], y.shape[-3], y.shape[-2]) + align
 
     def autotune(self, stream_ptr, table=None, reps=3):
         """Time every tile configuration of dh_conv2d_f32 for each distinct conv shape of this bound plan
@@ -484,7 +463,7 @@ class BoundPlan:
         so the choice never changes a result bit.  `table` (signature -> cfg) is filled / reused."""
         lib = self.lib
         table = {} if table is None else table
-        ncfgs = {'conv': lib.dh_conv2d_num_tile_cfgs(), 'sepconv': lib.dh_sepconv2d_num_tile_cfgs()}
+        ncfgs = {'conv': lib.dh_conv2d_num_tile_cfgs()}
         e0, e1 = C.c_void_p(), C.c_void_p()
         _lib.check(lib.dh_event_create(C.byref(e0)))
         _lib.check(lib.dh_event_create(C.byref(e1)))
@@ -492,7 +471,7 @@ class BoundPlan:
             if step.kind not in ncfgs:
                 continue
             ncfg = ncfgs[step.kind]
-            cargs = args[0]._obj.pw if step.kind == 'sepconv' else args[0]._obj
+            cargs = args[0]._obj
             sig = (self.n, step.kind) + self._conv_signature(step) + ((('u8',) if cargs.x_u8 else ())) + \
                 ((('bf16x3',) if cargs.w_split else ()))
             if cargs.w_split:
@@ -586,6 +565,17 @@ class BoundPlan:
 
 
 _GRAPH_GRAVEYARD = []
+_STAGING_THREADS = max(1, min(8, (os.cpu_count() or 2) // 2, int(os.environ.get('DEEPHAR_STAGING_THREADS', '6'))))
+_POOL = None
+
+
+def _staging_pool():
+    """Threads that copy / cast host arrays into pinned staging for Model.predict (run_pipelined); orchestration only."""
+    global _POOL
+    if _POOL is None:
+        from concurrent.futures import ThreadPoolExecutor
+        _POOL = ThreadPoolExecutor(max_workers=_STAGING_THREADS, thread_name_prefix='deephar-staging')
+    return _POOL
 
 
 class Executor:
@@ -737,21 +727,23 @@ class Executor:
 
     def run_pipelined(self, arrays, bs, u8_norm=None, verbose=0):
         """Forward over all rows of `arrays` (host arrays, equal leading dim) in chunks of `bs`, as a 3-stage pipeline:
-             host   : cast / copy chunk i+k into pinned staging      (overlaps the GPU working on chunk i)
+             host   : cast / copy chunk i+2 into pinned staging on a small THREAD POOL (row slices in parallel; the
+                      copy releases the GIL) while the main thread enqueues chunk i -- a float32 batch of 64 frames is
+                      50 MB, and one core writing pinned (fine-grained) host memory was the serial stage of the float32
+                      boundary (66 % of the device-resident rate over 2 048 frames before the pool)
              copy   : pinned -> device staging on a copy stream      (overlaps the graph replay of chunk i)
              compute: staging -> plan input (D2D), hipGraph replay, ONE D2H of the packed outputs of the whole model
                       (arena[0 : out_items * n]) into pinned memory.
-           The ring of staging slots is DEEP (up to DEEPHAR_PREDICT_DEPTH = 8 chunks in flight): on this stack every
-           host-side wait that actually has to block (hipEventSynchronize, hipStreamSynchronize, or polling a flag the
-           GPU writes) is followed by a 40-70 ms hole in the GPU's timeline, even though later chunks are already
-           queued (profiles/r02_predict_boundary.md) -- so the host enqueues ahead and waits as late as it can.
+           The ring of staging slots is DEEP (up to DEEPHAR_PREDICT_DEPTH = 8 chunks in flight, capped at 512 MB of
+           pinned staging per bound plan): on this stack every host-side wait that actually has to block is followed by
+           a 40-70 ms hole in the GPU's timeline, even though later chunks are already queued
+           (profiles/r02_predict_boundary.md) -- so the host enqueues ahead and waits as late as it can.
            Returns one np.float32 array per model output, rows in input order (keras Model.predict semantics:
            exp/common/*_tools.py; timing method of exp/pennaction/eval_speed2d.py:70-77)."""
         torch = _torch()
         total = arrays[0].shape[0]
         bs = int(min(bs, total))
         nchunks = (total + bs - 1) // bs
-        depth = max(2, min(nchunks, int(os.environ.get('DEEPHAR_PREDICT_DEPTH', '8'))))
         with torch.cuda.device(self.device):
             if self.bound:
                 self.sync_weights()
@@ -761,9 +753,16 @@ class Executor:
                 self._wstamp = self._weight_stamp()
             if getattr(self, 'copy_stream', None) is None:
                 self.copy_stream = torch.cuda.Stream(device=self.device)
-            io = self._io(bp, depth)
             want = torch.uint8 if bp.u8 is not None else torch.float32
+            slot_bytes = sum(bs * int(np.prod(v.shape)) for v in self.plan.inputs) * (1 if want == torch.uint8 else 4)
+            depth = max(2, min(nchunks, int(os.environ.get('DEEPHAR_PREDICT_DEPTH', '8')),
+                               max(2, (512 << 20) // max(slot_bytes, 1))))
+            io = self._io(bp, depth)
+            io['pending'] = [None] * len(io['pending'])        # a call that died mid-loop must not leak rows into this one
             results = []
+            ahead = min(2, depth - 1)                           # chunks staged ahead of the one being enqueued
+            pool = _staging_pool()
+            staged = {}
 
             def collect(slot):
                 m = io['pending'][slot]
@@ -772,11 +771,12 @@ class Executor:
                     results.append(self._host_outputs(bp, io['host_out'][slot], m))
                     io['pending'][slot] = None
 
-            for ci, start in enumerate(range(0, total, bs)):
-                slot = ci % depth
-                collect(slot)                               # chunk ci-depth used this slot
+            def stage(ci):
+                """Start the host-side copies of chunk ci into its slot; returns (m, on_dev, device sources, futures)."""
+                slot, start = ci % depth, ci * bs
+                collect(slot)                                   # chunk ci - depth used this slot (its H2D is long done)
                 m = min(bs, total - start)
-                on_dev = []
+                on_dev, dev_src, futs = [], [], []
                 for k, (v, arr) in enumerate(zip(self.plan.inputs, arrays)):
                     part = arr[start:start + m]
                     if tuple(part.shape[1:]) != tuple(v.shape):
@@ -785,28 +785,52 @@ class Executor:
                     if (src.dtype == torch.uint8) != (want == torch.uint8):
                         raise ValueError('plan bound for %s inputs, got %s' % (want, src.dtype))
                     on_dev.append(bool(src.is_cuda))
-                    if src.is_cuda:
-                        io['dev_in'][slot][k][:m].copy_(src)                      # caller already holds device data
-                    else:
-                        io['host_in'][slot][k][:m].copy_(src)                     # host-side cast (f64 -> f32) + pin
-                with torch.cuda.stream(self.copy_stream):
-                    for k in range(len(arrays)):
-                        if not on_dev[k]:
-                            io['dev_in'][slot][k][:m].copy_(io['host_in'][slot][k][:m], non_blocking=True)
-                    io['h2d'][slot].record(self.copy_stream)
-                with torch.cuda.stream(self.stream):
-                    self.stream.wait_event(io['h2d'][slot])                       # GPU-side wait
-                    for k, v in enumerate(self.plan.inputs):
-                        dst = bp.u8[id(v.buf)][0] if bp.u8 is not None else bp.tensor(v)
-                        dst[:m].copy_(io['dev_in'][slot][k][:m], non_blocking=True)
-                    self.forward(bp)
-                    io['host_out'][slot].copy_(bp.arena[:io['host_out'][slot].numel()], non_blocking=True)
-                    io['done'][slot].record(self.stream)
-                io['pending'][slot] = m
-                if verbose:
-                    print('%d/%d' % (start + m, total))
-            for k in range(depth):                                  # oldest pending chunk first
-                collect((nchunks + k) % depth)
+                    dev_src.append(src if src.is_cuda else None)
+                    if not src.is_cuda:                         # host-side cast (f64 -> f32) + pin, row slices in parallel
+                        dst = io['host_in'][slot][k]
+                        nsl = max(1, min(_STAGING_THREADS, src.numel() * src.element_size() >> 22, m))
+                        step = -(-m // nsl)
+                        for a0 in range(0, m, step):
+                            futs.append(pool.submit(dst[a0:a0 + step].copy_, src[a0:min(a0 + step, m)]))
+                return m, on_dev, dev_src, futs
+
+            try:
+                for ci in range(min(ahead, nchunks)):
+                    staged[ci] = stage(ci)
+                for ci in range(nchunks):
+                    if ci + ahead < nchunks:
+                        staged[ci + ahead] = stage(ci + ahead)
+                    slot = ci % depth
+                    m, on_dev, dev_src, futs = staged.pop(ci)
+                    for fu in futs:
+                        fu.result()
+                    with torch.cuda.stream(self.copy_stream):
+                        if any(on_dev):                         # the caller's device data may still be in flight on ITS stream
+                            self.copy_stream.wait_stream(torch.cuda.current_stream())
+                        for k in range(len(arrays)):
+                            src = dev_src[k] if on_dev[k] else io['host_in'][slot][k][:m]
+                            io['dev_in'][slot][k][:m].copy_(src, non_blocking=True)
+                        io['h2d'][slot].record(self.copy_stream)
+                    with torch.cuda.stream(self.stream):
+                        self.stream.wait_event(io['h2d'][slot])                       # GPU-side wait
+                        for k, v in enumerate(self.plan.inputs):
+                            dst = bp.u8[id(v.buf)][0] if bp.u8 is not None else bp.tensor(v)
+                            dst[:m].copy_(io['dev_in'][slot][k][:m], non_blocking=True)
+                        self.forward(bp)
+                        io['host_out'][slot].copy_(bp.arena[:io['host_out'][slot].numel()], non_blocking=True)
+                        io['done'][slot].record(self.stream)
+                    io['pending'][slot] = m
+                    if verbose:
+                        print('%d/%d' % (min((ci + 1) * bs, total), total))
+                for k in range(depth):                                  # oldest pending chunk first
+                    collect((nchunks + k) % depth)
+            finally:
+                for _, _, _, futs in staged.values():                   # (an exception mid-loop: let the copies finish)
+                    for fu in futs:
+                        fu.cancel() or fu.exception()
+                if any(p is not None for p in io['pending']):
+                    self.stream.synchronize()
+                    io['pending'] = [None] * len(io['pending'])
         nres = len(self.plan.outputs)
         return [np.concatenate([r[k] for r in results], axis=0) if len(results) > 1 else results[0][k]
                 for k in range(nres)]

@@ -13,8 +13,6 @@ Fusion rules (what the reference leaves to TensorFlow as separate kernels):
                 resolution; a free-standing UpSampling2D -> add becomes one upsample_add kernel.
   R4 concat   : producers write straight into the concatenation buffer at their channel offset
                 (reception.py:75,83,87); Lambda channel slices are pointer/ld views (reception.py:171-172).
-  R6 sepconv  : (optional, DEEPHAR_FUSE_SEPCONV=1) ReLU -> depthwise -> pointwise -> epilogue as one launch
-                (layers.py:74-80, 288-301); off by default, see Planner.__init__.
   R5 decoder  : channel soft-max + both lin_interpolation_2d + joint confidence (+ global max) on the same
                 maps are one soft-argmax kernel (blocks.py:306-343).
 All tensors are fp32; sizes are tracked per batch item so one plan serves any batch size.
@@ -81,11 +79,10 @@ class Step:
     def flops(self, n=1):
         """Algorithmic FLOPs (2*MAC) for n batch items (conv/GEMM-shaped steps only)."""
         a = self.attrs
-        if self.kind in ('conv', 'sepconv'):
+        if self.kind == 'conv':
             y = self.outs['y']
             m = y.npix // (4 if a.get('up2') else 1)
-            dw = 2.0 * n * m * a['Cin'] * a['dkh'] * a['dkw'] if self.kind == 'sepconv' else 0.0
-            return 2.0 * n * m * a['K'] * a['Cout'] + dw
+            return 2.0 * n * m * a['K'] * a['Cout']
         if self.kind == 'dwconv':
             y = self.outs['y']
             return 2.0 * n * y.npix * y.C * a['kh'] * a['kw']
@@ -129,19 +126,9 @@ class _Lazy:
         self.relu = relu
 
 
-def _fuse_sepconv_default():
-    import os
-    return os.environ.get('DEEPHAR_FUSE_SEPCONV', '0') == '1'
-
-
 class Planner:
-    def __init__(self, inputs, outputs, nstreams=1, fuse_sepconv=None):
+    def __init__(self, inputs, outputs, nstreams=1):
         self.nstreams = nstreams
-        # R6 (optional): SeparableConv2D as ONE launch (dh_sepconv2d_f32, depthwise evaluated as the A operand of the
-        # pointwise GEMM).  Bit-identical to the two-launch pair but measured 7-40 % SLOWER on gfx950: the fp32 MFMA
-        # leaves no issue slots for the depthwise stage (profiles/r02_sepconv_fusion_study.md), so it is off by default.
-        self.fuse_sepconv = _fuse_sepconv_default() if fuse_sepconv is None else bool(fuse_sepconv)
-        self.fuse_pool = os.environ.get('DEEPHAR_FUSE_POOL', '0') not in ('0', '')      # R7, off by default (see op_pool)
         self.producer = {}            # id(Value) -> the Step that writes it
         self.g_inputs = inputs
         self.g_outputs = outputs
@@ -314,8 +301,7 @@ class Planner:
                             t = a.outputs[0]
         return epi, t
 
-    def _emit_conv(self, x, pre_bn, pre_relu, param, a, out_t, name, dw=None):
-        """dw = (depthwise Param, node attrs): emit the fused separable step (kind 'sepconv') instead of a conv."""
+    def _emit_conv(self, x, pre_bn, pre_relu, param, a, out_t, name):
         epi, final_t = self._epilogue(out_t)
         y = self.out_value_for(final_t)
         attrs = dict(kh=a['kh'], kw=a['kw'], sh=a.get('sh', 1), sw=a.get('sw', 1), pt=a['pt'], pl=a['pl'],
@@ -331,10 +317,7 @@ class Planner:
             params['pre_bn'] = pre_bn
         if epi['post_bn'] is not None:
             params['post_bn'] = epi['post_bn']
-        if dw is not None:
-            params['dw'] = dw[0]
-            attrs.update(dkh=dw[1]['kh'], dkw=dw[1]['kw'], dpt=dw[1]['pt'], dpl=dw[1]['pl'])
-        self.emit('sepconv' if dw is not None else 'conv', ins, dict(y=y), attrs, params, name)
+        self.emit('conv', ins, dict(y=y), attrs, params, name)
         self.val[final_t.uid] = y
 
     def op_conv(self, node):
@@ -347,12 +330,9 @@ class Planner:
         layer = node.layers['sepconv']
         a = node.attrs
         pw = dict(kh=1, kw=1, sh=1, sw=1, pt=0, pl=0, filters=a['filters'])
-        h, w = node.inputs[0].shape[-3], node.inputs[0].shape[-2]
-        if self.fuse_sepconv and pre_bn is None and a['kh'] == a['kw'] and a['kh'] in (3, 5) and \
-                a['pt'] == (a['kh'] - 1) // 2 and a['pl'] == a['pt'] and x.C % 16 == 0 and x.ld % 4 == 0 and \
-                x.coff % 4 == 0 and h % 2 == 0 and w <= 32 and 128 % (2 * w) == 0:
-            self._emit_conv(x, None, pre_relu, layer.params[1], pw, node.outputs[0], node.name, dw=(layer.params[0], a))
-            return
+        # depthwise and pointwise stay two launches: a fused kernel (depthwise evaluated as the A operand of the MFMA
+        # GEMM) was built in round 2, bit-identical and 7-40 % slower -- nothing issues beside an fp32 MFMA on gfx950
+        # (profiles/r02_sepconv_fusion_study.md; the kernel lives in the history at commit 5d88aa8)
         mid = self.new_value(node.inputs[0].shape)
         params = dict(w=layer.params[0])
         if pre_bn is not None:
@@ -435,25 +415,8 @@ class Planner:
     def op_pool(self, node):
         x = self.materialize(node.inputs[0])
         y = self.out_value_for(node.outputs[0])
-        # R7 (DEEPHAR_FUSE_POOL=1): MaxPooling2D((2, 2)) of a convolution's output at 32 columns is written by that
-        # convolution's epilogue as a second output (dh_conv_args.y_pool) -- the stand-alone pool reads the whole tensor
-        # back from HBM (reception.py:105-116: every hourglass level is used at full AND at half resolution).
-        # Bit-identical, but measured neutral on the MPII model (4 834 vs 4 846 frames/s): in seven of eight blocks the
-        # producer is the K = 48 fReMap GEMM, itself bound by its epilogue, and the pooling pass costs it what the pool
-        # kernel cost.  Off by default.
-        a = node.attrs
-        prod = self.producer.get(id(x))
-        if self.fuse_pool and prod is not None and prod.kind == 'conv' and prod.outs.get('y') is x and \
-                'ypool' not in prod.outs and not prod.attrs.get('up2') and a.get('mode', 0) == 0 and \
-                (a['kh'], a['kw'], a['sh'], a['sw'], a['pt'], a['pl']) == (2, 2, 2, 2, 0, 0) and \
-                x.shape[-2] == 32 and x.shape[-3] % 2 == 0 and x.C % 4 == 0 and x.ld % 4 == 0 and y.ld % 4 == 0 and \
-                x.coff % 4 == 0 and y.coff % 4 == 0 and \
-                not split_k_rule(x.shape[-3] * x.shape[-2], prod.attrs['K'], prod.attrs['Cout'], prod.attrs['Cin']):
-            prod.outs['ypool'] = y
-            prod.attrs['pool2'] = 1
-            self.producer[id(y)] = prod
-            self.val[node.outputs[0].uid] = y
-            return
+        # (writing the 2x2 max-pool from the producing convolution's epilogue was built in round 2 and measured neutral:
+        # in seven of eight blocks the producer is the K = 48 fReMap GEMM, itself bound by its epilogue; removed)
         self.emit('pool', dict(x=x), dict(y=y), dict(node.attrs), name=node.name or 'pool')
         self.val[node.outputs[0].uid] = y
 
@@ -637,9 +600,9 @@ class Planner:
         self.plan.params = out
 
 
-def build_plan(inputs, outputs, nstreams=1, fuse_sepconv=None, gemm_precision='f32'):
+def build_plan(inputs, outputs, nstreams=1, gemm_precision='f32'):
     if gemm_precision not in ('f32', 'bf16x3'):
         raise ValueError("gemm_precision must be 'f32' or 'bf16x3', got %r" % (gemm_precision,))
-    plan = Planner(inputs, outputs, nstreams, fuse_sepconv).run()
+    plan = Planner(inputs, outputs, nstreams).run()
     plan.gemm_precision = gemm_precision
     return plan

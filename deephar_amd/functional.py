@@ -45,7 +45,7 @@ def pack_conv_weight(w_hwio, device='cuda'):
 
 def conv2d(x, w_hwio, strides=(1, 1), padding='same', pre_scale=None, pre_shift=None, pre_relu=False,
            post_scale=None, post_shift=None, post_relu=False, res1=None, res2=None, up2=False, tile_cfg=-1,
-           packed=None, in_lut=None, split=False, pool2=False):
+           packed=None, in_lut=None, split=False):
     """Fused conv (see dh_conv2d_f32).  x [N,H,W,Cin]; w_hwio numpy [kh,kw,Cin,Cout].  A uint8 `x` needs
     `in_lut` (float32 [Cin,256] device tensor, engine.executor.normalization_lut): bytes are normalised on load."""
     torch = _t()
@@ -87,12 +87,8 @@ def conv2d(x, w_hwio, strides=(1, 1), padding='same', pre_scale=None, pre_shift=
     a.pre_relu, a.post_relu, a.up2 = int(pre_relu), int(post_relu), int(up2)
     if x.dtype == torch.uint8:
         a.in_lut, a.x_u8 = _p(in_lut), 1
-    yp = None
-    if pool2:                                    # second output: MaxPooling2D((2, 2)) of y (dh_conv_args.y_pool)
-        yp = torch.empty((n, oh // 2, ow // 2, cout), dtype=torch.float32, device=x.device)
-        a.y_pool, a.ldyp = _p(yp), cout
     _lib.check(lib.dh_conv2d_f32(C.byref(a), tile_cfg, _stream()), 'dh_conv2d_f32')
-    return (y, yp) if pool2 else y
+    return y
 
 
 def normalize_u8(x, lut):
@@ -124,41 +120,6 @@ def dwconv2d(x, dw_kernel, pre_scale=None, pre_shift=None, pre_relu=False):
     a.N, a.H, a.W, a.C, a.ldx, a.ldy = n, h, w_, c, c, c
     a.KH, a.KW, a.PT, a.PL, a.pre_relu = kh, kw, pt, pl, int(pre_relu)
     _lib.check(lib.dh_dwconv2d_f32(C.byref(a), _stream()), 'dh_dwconv2d_f32')
-    return y
-
-
-def sepconv2d(x, dw_kernel, pw_kernel, pre_relu=False, post_scale=None, post_shift=None, post_relu=False, res1=None,
-              res2=None, up2=False, tile_cfg=-1):
-    """Fused SeparableConv2D (dh_sepconv2d_f32): [ReLU ->] depthwise K x K (stride 1, TF-SAME) -> pointwise 1x1
-    [-> BN affine -> + res1 -> (x2 up-sampling) + res2 -> ReLU] in one launch.  dw_kernel numpy [kh,kw,C,1],
-    pw_kernel numpy [1,1,C,Cout].  Raises DeepharHipError(rc=-2) for shapes the fused kernel does not cover."""
-    torch = _t()
-    _chk(x, post_scale, post_shift, res1, res2)
-    lib = _lib.load()
-    kh, kw, c, _ = dw_kernel.shape
-    n, h, w_, cx = x.shape
-    cout = pw_kernel.shape[-1]
-    assert cx == c and pw_kernel.shape[:3] == (1, 1, c)
-    pt, _, _ = same_pad(h, kh, 1)
-    pl, _, _ = same_pad(w_, kw, 1)
-    dwt = torch.from_numpy(np.ascontiguousarray(dw_kernel.reshape(kh * kw, c), np.float32)).to(x.device)
-    wt, kp, np_ = pack_conv_weight(pw_kernel, x.device)
-    up = 2 if up2 else 1
-    y = torch.empty((n, h * up, w_ * up, cout), dtype=torch.float32, device=x.device)
-    s = _lib.SepConvArgs()
-    a = s.pw
-    a.x, a.w, a.y = _p(x), _p(wt), _p(y)
-    a.post_scale, a.post_shift, a.res1, a.res2 = _p(post_scale), _p(post_shift), _p(res1), _p(res2)
-    a.N, a.H, a.W, a.Cin, a.ldx = n, h, w_, c, c
-    a.OH, a.OW, a.Cout, a.ldy = h, w_, cout, cout
-    a.KH, a.KW, a.SH, a.SW, a.PT, a.PL = 1, 1, 1, 1, 0, 0
-    a.K, a.Kp, a.Np = c, kp, np_
-    a.ldr1 = res1.shape[-1] if res1 is not None else 0
-    a.ldr2 = res2.shape[-1] if res2 is not None else 0
-    a.pre_relu, a.post_relu, a.up2 = int(pre_relu), int(post_relu), int(up2)
-    s.dw_w, s.DKH, s.DKW, s.DPT, s.DPL = _p(dwt), kh, kw, pt, pl
-    _lib.check(lib.dh_sepconv2d_f32(C.byref(s), tile_cfg, _stream()), 'dh_sepconv2d_f32')
-    torch.cuda.current_stream().synchronize()   # dwt / wt are temporaries
     return y
 
 

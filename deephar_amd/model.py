@@ -41,7 +41,6 @@ class Model:
         # uint8 inputs are raw frames: predict() normalises them on the GPU exactly like the reference's loaders do
         # on the host (utils/transform.normalize_channels(frame, channel_power), transform.py:212-231)
         self.channel_power = 1
-        self.fuse_sepconv = None      # None: DEEPHAR_FUSE_SEPCONV (default off); see engine/planner.py R6
         # 'f32' (default): every conv on the fp32 matrix path, an exact k-ordered fmaf chain.  'bf16x3': pointwise / K x K
         # GEMM-shaped convs split their fp32 operands exactly into three bf16 parts and run six partial products on the
         # bf16 matrix cores with fp32 accumulation (csrc/gemm1x1s.hip): same accuracy class, ~1.7x faster, not bit-identical
@@ -174,7 +173,7 @@ class Model:
         if self._plan is None:
             from .engine.planner import build_plan
             self._plan = build_plan(self.inputs, self.outputs, nstreams=self.num_streams,
-                                    fuse_sepconv=self.fuse_sepconv, gemm_precision=self.gemm_precision)
+                                    gemm_precision=self.gemm_precision)
         return self._plan
 
     @property

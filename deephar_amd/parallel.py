@@ -190,8 +190,7 @@ class ShardedClipModel:
         self.frame_model, self.head_model, self.info = split_frames(model, self.world)
         for stage in (self.frame_model, self.head_model):          # the stages run with the clip model's engine options
             if stage is not None:
-                stage.num_streams, stage.fuse_sepconv = model.num_streams, model.fuse_sepconv
-                stage.gemm_precision = model.gemm_precision
+                stage.num_streams, stage.gemm_precision = model.num_streams, model.gemm_precision
         self.frame_fn = frame_fn or self._frame_hip
         self.head_fn = head_fn or self._head_hip
         self.last_outputs = None

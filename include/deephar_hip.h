@@ -68,20 +68,13 @@ typedef struct dh_conv_args {
   int32_t x_u8; /* 1: x points to uint8 frames [N,H,W,ldx]; every byte goes through in_lut before the (optional)
                    BN prologue, zero padding is applied after it.  This is utils/transform.normalize_channels
                    (transform.py:212-231: /255, power, -0.5, *2 in float32) fused into the first convolution; only
-                   the general K x K path takes it (Cin % 4 != 0 or tile_cfg < dh_conv2d_num_tile_cfgs()/2) */
+                   the general K x K path takes it (tile_cfg < 0, or one of its tilings 0..8) */
   int32_t w_split; /* 1: `w` was packed by dh_conv2d_pack_weights_split_host (every weight split exactly into three bf16
                       parts) and the convolution runs on the bf16 matrix cores: fp32 activations are split the same way
                       on the fly, six of the nine partial products are accumulated in fp32 (gemm1x1s.hip).  Same
                       inputs / outputs / epilogue; per-product error <= 2^-23 relative, i.e. below the rounding of the
                       fp32 accumulation -- NOT bit-identical to w_split = 0.  Only shapes the LDS-DMA GEMM covers
                       (pointwise, or K x K with Cin % 32 == 0; 16-byte aligned x; no BN prologue), else DH_EUNSUPPORTED */
-  int32_t ldyp;
-  float* y_pool; /* optional second output: MaxPooling2D((2, 2)) of the convolution's FINAL output (after BN / residuals /
-                    ReLU), [N, OH/2, OW/2, Cout] with pixel pitch ldyp -- the hourglass reads every level both at full and
-                    at half resolution (reception.py:105-116: x = sep-residual(...); MaxPooling2D((2, 2))(x)), and a
-                    stand-alone pool has to read the whole tensor back.  Built for OW == 32, OH even, 16-byte aligned
-                    rows, no up2, on the tilings whose waves own 32-row blocks in pairs (an image row per wave, the pair
-                    pools through the epilogue's LDS slab); anything else returns DH_EUNSUPPORTED */
 } dh_conv_args;
 
 /* padded dims of the packed weight for a [KH,KW,Cin,Cout] (Keras HWIO) kernel */
@@ -102,6 +95,11 @@ int dh_conv2d_pick_tile_cfg(int M, int Cout);
  * Cin only, so that a layer's result bits never depend on tiling choice, batch size or alignment.  Such a layer takes
  * fp32-packed weights (w_split = 0) and ignores tile_cfg. */
 int dh_conv2d_uses_split_k(const dh_conv_args* a);
+/* 1 when dh_conv2d_f32 would accept this convolution with w_split = 1 (every field but `w` / `w_split` filled in as for
+ * the launch): an LDS-DMA GEMM shape (pointwise, or K x K with Cin % 32 == 0, no fused up-sampling), 16-byte aligned
+ * float input, no BN prologue, not a split-K layer, operands within the 32-bit buffer offsets of the kernel.  A
+ * binding asks this BEFORE it packs the weights, so that a layer is never bound with a packing its launch rejects. */
+int dh_conv2d_split_eligible(const dh_conv_args* a);
 int dh_conv2d_f32(const dh_conv_args* a, int tile_cfg, void* stream);
 
 /* Stand-alone version of the same normalisation for inputs that do not feed a convolution directly:
@@ -123,27 +121,6 @@ typedef struct dh_dw_args {
   int32_t pre_relu;
 } dh_dw_args;
 int dh_dwconv2d_f32(const dh_dw_args* a, void* stream);
-
-/* ---------------------------------------------------------------------------------------------------
- * keras SeparableConv2D in ONE launch (layers.sepconv2d, layers.py:74-80; separable_act_conv_bn :288-301;
- * reception._sepconv_residual, reception.py:43-59; common.residual_unit's 'depthwise' branch, common.py:47-48):
- * the depthwise K x K (K in {3, 5}, stride 1, TF-SAME, depth_multiplier 1) is evaluated on the fly as the A operand
- * of the pointwise GEMM, so the depthwise tensor never reaches HBM.
- *   `pw`  describes the POINTWISE convolution exactly as for dh_conv2d_f32 (KH = KW = 1, SH = SW = 1, no padding,
- *         K = Cin, packed weight, epilogue fields, up2) with x / H / W / Cin / ldx = the input of the depthwise
- *         stage; pw.pre_relu is applied to that input (ReLU -> depthwise -> pointwise); pw.pre_scale must be NULL.
- *   `dw_w` [DKH*DKW][Cin] depthwise taps (= Keras [KH,KW,C,1]), (DPT, DPL) = explicit top / left padding.
- * Results are bit-identical to dh_dwconv2d_f32 followed by dh_conv2d_f32 (same tap order, same K order).
- * Returns DH_EUNSUPPORTED for shapes outside the fused kernel (callers fall back to the pair).
- * tile_cfg < 0: library heuristic; 0..dh_sepconv2d_num_tile_cfgs()-1 forces a tiling (autotuning hook).
- * ------------------------------------------------------------------------------------------------- */
-typedef struct dh_sepconv_args {
-  dh_conv_args pw;
-  const float* dw_w;
-  int32_t DKH, DKW, DPT, DPL;
-} dh_sepconv_args;
-int dh_sepconv2d_num_tile_cfgs(void);
-int dh_sepconv2d_f32(const dh_sepconv_args* a, int tile_cfg, void* stream);
 
 /* MaxPooling2D (reception.py:74,86,108,115; layers.py:92-97), padding cells ignored;
  * mode 1 = layers.max_min_pooling (layers.py:411-425): maxpool(x) - maxpool(-x) */

@@ -455,45 +455,6 @@ def test_hip_matches_real_keras_outputs(tag, hip_lib, cuda):
             assert float(np.max(np.abs(h - r))) <= 4 * PX_TOL, (tag, k)
 
 
-def test_fused_sepconv_plan_is_bit_identical(hip_lib, cuda):
-    """Planner rule R6 (DEEPHAR_FUSE_SEPCONV=1 / Model.fuse_sepconv): every SeparableConv2D as one dh_sepconv2d_f32
-    launch.  Same taps order, same K order -> the model's outputs do not change by a bit (it is off by default only
-    because it is slower on gfx950: profiles/r02_sepconv_fusion_study.md)."""
-    from collections import Counter
-    x = np.random.default_rng(9).uniform(-1, 1, (3, 256, 256, 3)).astype(np.float32)
-    m, _ = _build(2, 2, 16, num_context_per_joint=2)
-    m.fuse_sepconv, m.gemm_precision = False, 'f32'      # (the fused kernel is an fp32-MFMA kernel)
-    ref = m.predict(x, batch_size=3)
-    assert Counter(s.kind for s in m.plan.steps)['dwconv'] == 17
-    f, _ = _build(2, 2, 16, num_context_per_joint=2)
-    f.fuse_sepconv, f.gemm_precision = True, 'f32'
-    kinds = Counter(s.kind for s in f.plan.steps)
-    assert kinds['sepconv'] == 17 and kinds['dwconv'] == 0
-    got = f.predict(x, batch_size=3)
-    for a, b in zip(ref, got):
-        assert np.array_equal(a, b)
-
-
-def test_pooled_epilogue_plan_is_bit_identical(hip_lib, cuda, monkeypatch):
-    """Planner rule R7 (MaxPooling2D written by the producing convolution's epilogue) changes no result bit, in either
-    GEMM mode."""
-    from deephar_amd.models import reception
-    for mode in ('f32', 'bf16x3'):
-        outs = {}
-        for fuse in ('1', '0'):
-            monkeypatch.setenv('DEEPHAR_FUSE_POOL', fuse)
-            m, _ = _build(2, 3, 16, num_context_per_joint=2)
-            m.gemm_precision = mode
-            x = np.random.default_rng(3).uniform(-1, 1, (3, 256, 256, 3)).astype(np.float32)
-            outs[fuse] = m.predict(x, batch_size=3)
-            n_pool = sum(1 for s in m.plan.steps if s.kind == 'pool' and s.ins['x'].shape[-2] == 32)
-            n_fused = sum(1 for s in m.plan.steps if s.kind == 'conv' and 'ypool' in s.outs)
-            assert (n_fused, n_pool) == ((3, 0) if fuse == '1' else (0, 3)), (mode, fuse, n_fused, n_pool)
-        monkeypatch.delenv('DEEPHAR_FUSE_POOL')
-        for a, b in zip(outs['1'], outs['0']):
-            assert np.array_equal(a, b), mode
-
-
 def test_keras_h5_weight_files_drive_the_gpu_model(hip_lib, cuda, tmp_path):
     """SURVEY.md 8f rank 1 on the GPU: a Keras-layout .h5 written by save_weights is loaded BY ORDER into a fresh
     ReceptionNet (eval_mpii_singleperson.py:54) and BY NAME into a fresh SPNet (eval_penn_multitask.py:76) whose weights

@@ -28,7 +28,7 @@ def test_ctypes_structs_match_header_layout(hip_lib, tmp_path):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     header = open(os.path.join(root, 'include', 'deephar_hip.h')).read()
     pairs = {'dh_conv_args': _lib.ConvArgs, 'dh_dw_args': _lib.DwArgs, 'dh_pool_args': _lib.PoolArgs,
-             'dh_elt_args': _lib.EltArgs, 'dh_sam_args': _lib.SamArgs, 'dh_sepconv_args': _lib.SepConvArgs}
+             'dh_elt_args': _lib.EltArgs, 'dh_sam_args': _lib.SamArgs}
     structs = set(re.findall(r'typedef struct (dh_\w+_args)', header))
     assert structs == set(pairs), structs ^ set(pairs)
     lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "deephar_hip.h"', 'int main(void) {']
@@ -132,31 +132,6 @@ def test_planner_fusion_rules():
     assert (sams[0].ins['h'].coff, sams[0].ins['h'].ld, sams[0].ins['h'].C) == (0, 48, 16)
     assert (sams[1].ins['h'].coff, sams[1].ins['h'].C) == (16, 32)
     assert sams[0].outs['conf_raw'].ld == 3 and sams[0].outs['conf_raw'].coff == 2
-
-
-def test_planner_pooled_output_rule(monkeypatch):
-    """R7 (DEEPHAR_FUSE_POOL=1): the 32-column MaxPooling2D becomes a second output of the convolution that feeds it; same
-    algorithmic FLOPs, one launch and one full-resolution read less per block, and the memory plan stays sound."""
-    base = _mpii(2).plan
-    monkeypatch.setenv('DEEPHAR_FUSE_POOL', '1')
-    plan = _mpii(2).plan
-    fused = [s for s in plan.steps if s.kind == 'conv' and 'ypool' in s.outs]
-    assert len(fused) == 2 and len(plan.steps) == len(base.steps) - 2
-    for s in fused:
-        y, yp = s.outs['y'], s.outs['ypool']
-        assert y.shape[-2] == 32 and yp.shape[-3:] == (y.shape[-3] // 2, 16, y.C) and s.attrs['pool2'] == 1
-    assert not any(s.kind == 'pool' and s.ins['x'].shape[-2] == 32 for s in plan.steps)
-    assert sum(s.flops() for s in plan.steps) == sum(s.flops() for s in base.steps)
-    assert sum(s.bytes() for s in plan.steps) < sum(s.bytes() for s in base.steps)
-    for i, s in enumerate(plan.steps):
-        for v in list(s.ins.values()) + list(s.outs.values()):
-            assert v.buf.start <= i <= v.buf.end
-    bufs = plan.bufs
-    for i, a in enumerate(bufs):
-        for b in bufs[i + 1:]:
-            live = not (a.end < b.start or b.end < a.start)
-            space = not (a.offset + a.items <= b.offset or b.offset + b.items <= a.offset)
-            assert not (live and space)
 
 
 def test_memory_plan_has_no_live_overlap():
@@ -338,6 +313,42 @@ def test_split_k_rule_matches_the_library(hip_lib):
     a.w_split = 1
     assert hip_lib.dh_conv2d_uses_split_k(C.byref(a)) == 0            # split-packed weights never take that kernel
     assert n > 500
+
+
+def test_split_eligibility_is_the_librarys_answer(hip_lib):
+    """dh_conv2d_split_eligible (asked by the executor before it packs a layer's weights for bf16x3 mode):
+    LDS-DMA GEMM shapes with an aligned float input and no BN prologue, not split-K layers, and -- what the Python
+    mirror used to miss -- operands inside the kernel's 32-bit buffer offsets.  No launch is made."""
+    import ctypes as C
+    from deephar_amd import _lib
+
+    def args(n=64, h=32, w=32, cin=576, cout=576, k=1, ldx=None, xptr=256):
+        a = _lib.ConvArgs()
+        a.x, a.y = xptr, 1 << 20
+        a.N, a.H, a.W, a.Cin, a.ldx, a.OH, a.OW, a.Cout, a.ldy = n, h, w, cin, ldx or cin, h, w, cout, cout
+        a.KH = a.KW = k
+        a.SH = a.SW = 1
+        a.PT = a.PL = (k - 1) // 2
+        a.K = k * k * cin
+        kp, np_ = C.c_int(), C.c_int()
+        assert hip_lib.dh_conv2d_packed_dims(k, k, cin, cout, C.byref(kp), C.byref(np_)) == 0
+        a.Kp, a.Np = kp.value, np_.value
+        return a
+    ok = lambda a: hip_lib.dh_conv2d_split_eligible(C.byref(a))
+    assert ok(args()) == 1                                    # the dominant pointwise GEMM
+    assert ok(args(cin=64, cout=96, k=3, h=64, w=64)) == 1    # stem K x K, Cin % 32 == 0
+    assert ok(args(cin=48, cout=96, k=3)) == 0                # K x K with Cin % 32 != 0
+    assert ok(args(xptr=260)) == 0                            # input view not 16-byte aligned
+    assert ok(args(ldx=578)) == 0                             # pixel pitch not a multiple of 4 floats
+    a = args()
+    a.pre_scale = a.pre_shift = 4096
+    assert ok(a) == 0                                         # BN prologue
+    a = args()
+    a.x_u8 = 1
+    assert ok(a) == 0
+    assert ok(args(h=16, w=16, cin=256, cout=256, k=3)) == 0  # an action-head conv: the split-K kernel (fp32 packing)
+    assert ok(args(n=1700)) == 1 and ok(args(n=1710)) == 0    # 1 710 x 32 x 32 x 576 x 4 B > 0xf0000000: fp32 fallback
+    assert hip_lib.dh_conv2d_split_eligible(None) == 0
 
 
 def test_integration_guide_declares_the_whole_conv_struct():

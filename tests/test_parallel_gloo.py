@@ -114,13 +114,13 @@ def test_split_frames_partitions_merge_and_spnet():
 
 def test_stage_models_inherit_engine_options():
     """The frame / head stages of a sharded clip model run with the clip model's engine options (GEMM precision,
-    stream count, fusion switch): bench.py --gemm bf16x3 --workload penn_merge must not silently run fp32 stages."""
+    stream count): bench.py --gemm bf16x3 --workload penn_merge must not silently run fp32 stages."""
     from deephar_amd import parallel
     m, _ = _build()
-    m.gemm_precision, m.num_streams, m.fuse_sepconv = 'bf16x3', 1, False
+    m.gemm_precision, m.num_streams = 'bf16x3', 1
     sh = parallel.ShardedClipModel(m, rank=0, world=2, frame_fn=lambda x: x, head_fn=lambda t: t)
     for stage in (sh.frame_model, sh.head_model):
-        assert (stage.gemm_precision, stage.num_streams, stage.fuse_sepconv) == ('bf16x3', 1, False)
+        assert (stage.gemm_precision, stage.num_streams) == ('bf16x3', 1)
         assert stage.plan.gemm_precision == 'bf16x3'
 
 

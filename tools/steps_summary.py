@@ -7,7 +7,7 @@ tot = sum(r['ms'] for r in rows)
 g = collections.OrderedDict()
 for r in rows:
     o = r['out'] or []
-    key = (r['kernel'].split('<')[0] if r['kind'] in ('conv', 'sepconv') else r['kind'], tuple(o[-3:]), round(r['gflop'], 1))
+    key = (r['kernel'].split('<')[0] if r['kind'] == 'conv' else r['kind'], tuple(o[-3:]), round(r['gflop'], 1))
     e = g.setdefault(key, [0, 0.0, 0.0, r['kernel']])
     e[0] += 1; e[1] += r['ms']; e[2] += r['gflop']
 print('total %.3f ms over %d launches' % (tot, len(rows)))
