@@ -443,8 +443,8 @@ def test_conv2d_split_k_kernel(case, hip_lib, cuda):
 
 @pytest.mark.parametrize('case', SPLIT_CASES)
 def test_conv2d_dma_gemm_tilings_bitwise(case, hip_lib, cuda):
-    """The fp32 LDS-DMA GEMM family (cfg 9..19, incl. the wide 32 x 192 tilings with their 16-k K-steps and two-slice
-    epilogue) on the same shapes: pointwise, K x K, strided, fused up-sampling, ragged tails -- all bit-identical."""
+    """The fp32 LDS-DMA GEMM family (cfg 9..17) on the same shapes: pointwise, K x K, strided, fused up-sampling, ragged
+    tails -- all tilings bit-identical."""
     from deephar_amd import functional as F
     n, h, w, cin, cout, ks, st, relu, res, up2 = case
     rng = np.random.default_rng(sum(int(v) for v in case) + 1)
@@ -465,7 +465,7 @@ def test_conv2d_dma_gemm_tilings_bitwise(case, hip_lib, cuda):
         except Exception as e:
             assert 'rc=-2' in str(e), e
     torch.cuda.synchronize()
-    assert 18 in outs and 19 in outs and len(outs) >= 4
+    assert len(outs) >= 4
     first = next(iter(outs.values()))
     for cfg, y in outs.items():
         assert torch.equal(y, first), 'DMA GEMM tiling %d differs' % cfg
