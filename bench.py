@@ -157,6 +157,8 @@ def kernel_name(s):
         return 'conv (library-picked tiling)'
     b = lambda v: 'true' if v else 'false'
     a = s.attrs
+    if a.get('w_split') == 2:
+        return 'conv_halo_kernel<%d, %d, %s>' % (a['kw'], max(cfg, 0) + 1, b(a['pre_relu']))
     if a.get('w_split'):
         kxk = not (a['kh'] == a['kw'] == 1 and a['sh'] == a['sw'] == 1 and a['pt'] == a['pl'] == 0)
         if cfg in SPLIT_WIDE:

@@ -57,6 +57,8 @@ SIGNATURES = {
     'dh_conv2d_pick_tile_cfg': (C.c_int, [C.c_int, C.c_int]),
     'dh_conv2d_uses_split_k': (C.c_int, [C.POINTER(ConvArgs)]),
     'dh_conv2d_split_eligible': (C.c_int, [C.POINTER(ConvArgs)]),
+    'dh_conv2d_halo_eligible': (C.c_int, [C.POINTER(ConvArgs)]),
+    'dh_conv2d_num_halo_tile_cfgs': (C.c_int, []),
     'dh_conv2d_f32': (C.c_int, [C.POINTER(ConvArgs), C.c_int, vp]),
     'dh_normalize_u8_f32': (C.c_int, [vp, vp, vp, C.c_int64, C.c_int, vp]),
     'dh_dwconv2d_f32': (C.c_int, [C.POINTER(DwArgs), vp]),

@@ -280,6 +280,7 @@ int gemm1x1_split_num_cfgs();
 int gemm1x1_num_cfgs();
 bool conv_is_skinny(const ConvArgs& a);
 int launch_conv_splitk(const ConvArgs& a, hipStream_t s);
+int launch_conv_halo(const ConvArgs& a, int cfg, int epi, hipStream_t s);
 
 // cfg 0..8: general implicit-GEMM kernel; cfg 9..17: the same tile shapes on the LDS-DMA kernel
 int conv_igemm_num_cfgs() { return kNumCfgs + gemm1x1_num_cfgs(); }
@@ -310,15 +311,16 @@ int launch_conv_igemm(const ConvArgs& a, int cfg, hipStream_t s) {
   // tiny output, long reduction: the in-work-group split-K kernel, whatever tiling was asked for (shape rule: the
   // result bits of a layer must not depend on a timing-based choice)
   if (conv_is_skinny(a)) return cfg < kNumCfgs + gemm1x1_num_cfgs() ? launch_conv_splitk(a, s) : DH_EINVAL;
-  if (cfg < 0)
-    cfg = conv_igemm_pick_cfg(a.N * a.OH * a.OW, a.Cout) + (!a.w_split && !a.x_u8 && gemm1x1_eligible(a) ? kNumCfgs : 0);
-  if (!a.w_split && cfg >= kNumCfgs + gemm1x1_num_cfgs()) return DH_EINVAL;
-  if (a.x_u8 && cfg >= kNumCfgs) return DH_EUNSUPPORTED;
   auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
   const int epi = (a.Cout % 4 == 0) && (a.ldy % 4 == 0) && al16(a.y) &&
                   (a.res1 == nullptr || (a.ldr1 % 4 == 0 && al16(a.res1))) &&
                   (a.res2 == nullptr || (a.ldr2 % 4 == 0 && al16(a.res2))) &&
                   (a.post_scale == nullptr || (al16(a.post_scale) && al16(a.post_shift)));
+  if (a.w_split == 2) return launch_conv_halo(a, cfg, epi, s);   // chunk-major fp32 packing: the halo-resident kernel only
+  if (cfg < 0)
+    cfg = conv_igemm_pick_cfg(a.N * a.OH * a.OW, a.Cout) + (!a.w_split && !a.x_u8 && gemm1x1_eligible(a) ? kNumCfgs : 0);
+  if (!a.w_split && cfg >= kNumCfgs + gemm1x1_num_cfgs()) return DH_EINVAL;
+  if (a.x_u8 && cfg >= kNumCfgs) return DH_EUNSUPPORTED;
   if (a.w_split) {                       // split-bf16 weights: only the LDS-DMA GEMM family reads that packing
     if (a.x_u8 || !gemm1x1_eligible(a)) return DH_EUNSUPPORTED;
     if (cfg >= gemm1x1_split_num_cfgs()) return DH_EINVAL;

@@ -20,6 +20,8 @@ int conv_igemm_num_cfgs();
 bool conv_is_skinny(const ConvArgs& a);
 int gemm1x1_split_num_cfgs();
 bool gemm1x1_split_eligible(const ConvArgs& a);
+bool conv_halo_eligible(const ConvArgs& a);
+int conv_halo_num_cfgs();
 int launch_dwconv(const DwArgs& a, hipStream_t s);
 int launch_pool(const PoolArgs& a, hipStream_t s);
 int launch_upsample2x_add(const float* a, int lda, const float* b, int ldb, float* y, int ldy, int N, int H,

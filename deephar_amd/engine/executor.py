@@ -42,12 +42,14 @@ class WeightStore:
                                'deephar_amd.weights.init_synthetic(model) before predict' % p.key)
         return p.value
 
-    def conv_weight(self, p, split=False):
-        """split=True: the split-bf16 packing of dh_conv_args.w_split (kept next to the fp32 packing when both are in use)."""
-        key = (id(p), bool(split))
+    def conv_weight(self, p, split=0):
+        """split = dh_conv_args.w_split: 0 fp32 tap-major, 1 the split-bf16 packing, 2 fp32 chunk-major (halo-resident
+        K x K kernel); different packings of one Param are kept side by side when several are in use."""
+        key = (id(p), int(split))
         ent = self.conv.get(key)
         if ent is None or ent[3] != p.version:
-            packed, kp, np_ = (packing.pack_conv_split if split else packing.pack_conv)(self._require(p))
+            packer = {0: packing.pack_conv, 1: packing.pack_conv_split, 2: packing.pack_conv_halo}[int(split)]
+            packed, kp, np_ = packer(self._require(p))
             if ent is None:
                 ent = (self._dev(packed), kp, np_, p.version)
             else:
@@ -180,14 +182,16 @@ class BoundPlan:
         for step in plan.steps:
             self._bind(step)
 
-    def split_ok(self, args):
-        """Does this conv step run on the bf16 matrix cores (plan.gemm_precision == 'bf16x3')?  The LIBRARY decides
-        (dh_conv2d_split_eligible: LDS-DMA GEMM shapes, aligned float input, no BN prologue, not a split-K layer, 32-bit
-        offset limits), asked with the launch's own argument struct before the weights are packed -- a layer is never
-        bound with a packing its launch would reject."""
-        if getattr(self.plan, 'gemm_precision', 'f32') != 'bf16x3':
-            return False
-        return bool(self.lib.dh_conv2d_split_eligible(C.byref(args)))
+    def weight_layout(self, args):
+        """dh_conv_args.w_split of a conv step: 1 = split-bf16 (plan.gemm_precision == 'bf16x3' and the library takes the
+        layer: dh_conv2d_split_eligible), 2 = fp32 chunk-major for the halo-resident K x K kernel
+        (dh_conv2d_halo_eligible: a rule on the per-frame geometry), else 0.  The LIBRARY decides, asked with the launch's
+        own argument struct before the weights are packed -- a layer is never bound with a packing its launch rejects."""
+        if getattr(self.plan, 'gemm_precision', 'f32') == 'bf16x3' and self.lib.dh_conv2d_split_eligible(C.byref(args)):
+            return 1
+        if os.environ.get('DEEPHAR_HALO_CONV', '1') != '0' and self.lib.dh_conv2d_halo_eligible(C.byref(args)):
+            return 2
+        return 0
 
     # ---- views -------------------------------------------------------------------------------------------
     def ptr(self, v):
@@ -242,7 +246,7 @@ class BoundPlan:
             if self.u8 is not None and id(x.buf) in self.u8 and self.u8[id(x.buf)][2]:
                 buf, lut, _ = self.u8[id(x.buf)]
                 args.x, args.in_lut, args.x_u8 = buf.data_ptr(), lut.data_ptr(), 1
-            split = self.split_ok(args)                # every field but w / w_split is final here
+            split = self.weight_layout(args)           # every field but w / w_split is final here
             wt, kp, np_ = self.store.conv_weight(s.params['w'], split=split)
             assert (kp, np_) == (args.Kp, args.Np)
             args.w, args.w_split = wt.data_ptr(), int(split)
@@ -473,9 +477,9 @@ class BoundPlan:
             ncfg = ncfgs[step.kind]
             cargs = args[0]._obj
             sig = (self.n, step.kind) + self._conv_signature(step) + ((('u8',) if cargs.x_u8 else ())) + \
-                ((('bf16x3',) if cargs.w_split else ()))
+                ((({1: 'bf16x3', 2: 'halo'}[cargs.w_split],) if cargs.w_split else ()))
             if cargs.w_split:
-                ncfg = lib.dh_conv2d_num_split_tile_cfgs()
+                ncfg = lib.dh_conv2d_num_halo_tile_cfgs() if cargs.w_split == 2 else lib.dh_conv2d_num_split_tile_cfgs()
             if step.kind == 'conv' and lib.dh_conv2d_uses_split_k(args[0]):
                 step.attrs['tile_cfg'] = -1                      # shape rule: split-K kernel, no tilings to choose from
                 step.attrs['split_k'] = True

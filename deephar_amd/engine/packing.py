@@ -19,6 +19,25 @@ def pack_conv(w_hwio):
     return out, kp.value, np_.value
 
 
+HALO_CHUNK = 16      # channels per resident chunk of csrc/conv_halo.hip
+
+
+def halo_order(w_hwio):
+    """HWIO kernel -> the [1, 1, K, Cout] kernel whose K runs chunk-major, [Cin/16][KH][KW][16], the order in which the
+    halo-resident K x K kernel sums (dh_conv_args.w_split = 2, include/deephar_hip.h: dh_conv2d_halo_eligible)."""
+    w = np.ascontiguousarray(w_hwio, dtype=np.float32)
+    kh, kw, cin, cout = w.shape
+    if cin % HALO_CHUNK:
+        raise ValueError('chunk-major packing needs Cin %% %d == 0, got %d' % (HALO_CHUNK, cin))
+    w = w.reshape(kh, kw, cin // HALO_CHUNK, HALO_CHUNK, cout).transpose(2, 0, 1, 3, 4)
+    return np.ascontiguousarray(w).reshape(1, 1, kh * kw * cin, cout)
+
+
+def pack_conv_halo(w_hwio):
+    """Keras HWIO conv kernel -> ([Kp/4][Np][4] float32, Kp, Np) with K chunk-major (see halo_order)."""
+    return pack_conv(halo_order(w_hwio))
+
+
 def unpack_conv(packed, kh, kw, cin, cout):
     """Inverse of pack_conv (tests)."""
     k = kh * kw * cin

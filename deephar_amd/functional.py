@@ -45,7 +45,7 @@ def pack_conv_weight(w_hwio, device='cuda'):
 
 def conv2d(x, w_hwio, strides=(1, 1), padding='same', pre_scale=None, pre_shift=None, pre_relu=False,
            post_scale=None, post_shift=None, post_relu=False, res1=None, res2=None, up2=False, tile_cfg=-1,
-           packed=None, in_lut=None, split=False):
+           packed=None, in_lut=None, split=False, halo=False):
     """Fused conv (see dh_conv2d_f32).  x [N,H,W,Cin]; w_hwio numpy [kh,kw,Cin,Cout].  A uint8 `x` needs
     `in_lut` (float32 [Cin,256] device tensor, engine.executor.normalization_lut): bytes are normalised on load."""
     torch = _t()
@@ -70,11 +70,14 @@ def conv2d(x, w_hwio, strides=(1, 1), padding='same', pre_scale=None, pre_shift=
     if split and packed is None:
         pk, kp, np_ = packing.pack_conv_split(np.asarray(w_hwio, np.float32))
         packed = (torch.from_numpy(pk).to(x.device), kp, np_)
+    if halo and packed is None:                  # chunk-major fp32 packing for the halo-resident K x K kernel
+        pk, kp, np_ = packing.pack_conv_halo(np.asarray(w_hwio, np.float32))
+        packed = (torch.from_numpy(pk).to(x.device), kp, np_)
     wt, kp, np_ = packed if packed is not None else pack_conv_weight(w_hwio, x.device)
     up = 2 if up2 else 1
     y = torch.empty((n, oh * up, ow * up, cout), dtype=torch.float32, device=x.device)
     a = _lib.ConvArgs()
-    a.w_split = int(split)
+    a.w_split = 2 if halo else int(split)
     a.x, a.w, a.y = _p(x), _p(wt), _p(y)
     a.pre_scale, a.pre_shift, a.post_scale, a.post_shift = _p(pre_scale), _p(pre_shift), _p(post_scale), _p(post_shift)
     a.res1, a.res2 = _p(res1), _p(res2)

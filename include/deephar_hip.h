@@ -69,7 +69,9 @@ typedef struct dh_conv_args {
                    BN prologue, zero padding is applied after it.  This is utils/transform.normalize_channels
                    (transform.py:212-231: /255, power, -0.5, *2 in float32) fused into the first convolution; only
                    the general K x K path takes it (tile_cfg < 0, or one of its tilings 0..8) */
-  int32_t w_split; /* 1: `w` was packed by dh_conv2d_pack_weights_split_host (every weight split exactly into three bf16
+  int32_t w_split; /* weight layout.  0: fp32, [Kp/4][Np][4], K tap-major.  2: fp32, same container, K chunk-major for the
+                      halo-resident K x K kernel (see dh_conv2d_halo_eligible).
+                      1: `w` was packed by dh_conv2d_pack_weights_split_host (every weight split exactly into three bf16
                       parts) and the convolution runs on the bf16 matrix cores: fp32 activations are split the same way
                       on the fly, six of the nine partial products are accumulated in fp32 (gemm1x1s.hip).  Same
                       inputs / outputs / epilogue; per-product error <= 2^-23 relative, i.e. below the rounding of the
@@ -100,6 +102,16 @@ int dh_conv2d_uses_split_k(const dh_conv_args* a);
  * float input, no BN prologue, not a split-K layer, operands within the 32-bit buffer offsets of the kernel.  A
  * binding asks this BEFORE it packs the weights, so that a layer is never bound with a packing its launch rejects. */
 int dh_conv2d_split_eligible(const dh_conv_args* a);
+/* 1 when this convolution belongs to the halo-resident K x K kernel (conv_halo.hip): dense K x K, stride 1, Cin % 16
+ * == 0 but Cin % 32 != 0 (the layers the LDS-DMA tap-major kernel cannot take), maps of >= 1024 pixels per frame whose
+ * rows tile into runs of 128 output pixels, 16-byte aligned float input, no BN prologue / fused up-sampling.  (The
+ * kernel itself also runs Cin % 32 == 0 when asked with w_split = 2.)  A rule on the per-frame geometry only -- never on the batch size or on timing --
+ * because that kernel sums K chunk-major ([16-channel chunk][kh][kw][16]) and its results differ in the last bits
+ * from the tap-major kernels'.  Such a layer is launched with w_split = 2 and weights packed in that K order: HWIO
+ * re-ordered to [Cin/16][KH][KW][16] rows, then dh_conv2d_pack_weights_host with (1, 1, KH*KW*Cin, Cout);
+ * tile_cfg in [0, dh_conv2d_num_halo_tile_cfgs()) or < 0. */
+int dh_conv2d_halo_eligible(const dh_conv_args* a);
+int dh_conv2d_num_halo_tile_cfgs(void);
 int dh_conv2d_f32(const dh_conv_args* a, int tile_cfg, void* stream);
 
 /* Stand-alone version of the same normalisation for inputs that do not feed a convolution directly:

@@ -355,6 +355,89 @@ def test_kxk_conv_on_the_dma_kernel(case, cfg, hip_lib, cuda):
     _close(a, ref, atol=5e-5, what='kxk dma conv')
 
 
+# ---- halo-resident K x K kernel (dh_conv_args.w_split = 2, conv_halo.hip) ------------------------------------------------
+HALO_CASES = [
+    # n, h, w, cin, cout, kh, kw, relu prologue, residual
+    (2, 128, 128, 32, 64, 3, 3, False, False),      # ReceptionNet stem: conv_bn_act(x, 64, (3, 3)) at 128 x 128
+    (1, 128, 128, 32, 32, 3, 3, False, True),       # ... and its 32-channel sibling; one tile = one image row
+    (2, 64, 64, 64, 96, 3, 3, False, False),        # stem branch a / b: conv_bn(., 96, (3, 3)); tile = 2 rows
+    (2, 64, 64, 64, 64, 5, 1, False, True),         # stem: (5, 1) and (1, 5)
+    (2, 64, 64, 64, 64, 1, 5, True, False),
+    (1, 32, 32, 144, 288, 3, 3, True, True),        # SPNet res3 / res4 conv2: Cin = 144 = 9 chunks, tile = 4 rows
+    (1, 128, 128, 48, 96, 3, 3, True, False),       # SPNet res0 conv2: Cin = 48
+    (3, 32, 32, 32, 40, 3, 3, False, True),         # ragged Cout
+    (1, 16, 256, 32, 64, 3, 3, True, False),        # rows wider than a tile: two 128-column runs per row
+    (2, 32, 32, 64, 96, 5, 5, True, True),          # 5 x 5
+]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('case', HALO_CASES)
+def test_conv2d_halo_kernel(case, hip_lib, cuda):
+    """Dense K x K convolutions with the input halo tile resident in LDS (chunk-major K order, w_split = 2): against the
+    fp64 oracle with the fused ReLU prologue / BN / residual / ReLU epilogue; its three tilings bit-identical; a frame's
+    result does not depend on the batch it sits in; the library's eligibility rule takes exactly these layers."""
+    import ctypes as C
+    from deephar_amd import _lib, functional as F
+    n, h, w, cin, cout, kh, kw, relu, res = case
+    rng = np.random.default_rng(sum(int(v) for v in case))
+    x = _rand(rng, (n, h, w, cin))
+    k = _rand(rng, (kh, kw, cin, cout), np.sqrt(1.0 / (kh * kw * cin)))
+    qs, qb = rng.uniform(0.5, 1.5, cout).astype(np.float32), _rand(rng, (cout,), 0.1)
+    r1 = _rand(rng, (n, h, w, cout)) if res else None
+    d = lambda a: None if a is None else torch.from_numpy(a).to(cuda)
+    kw_ = dict(pre_relu=relu, post_scale=d(qs), post_shift=d(qb), res1=d(r1), post_relu=True)
+    outs = []
+    for cfg in range(-1, hip_lib.dh_conv2d_num_halo_tile_cfgs()):
+        try:
+            outs.append(F.conv2d(d(x), k, halo=True, tile_cfg=cfg, **kw_))
+        except Exception as e:                   # a tiling whose stages do not fit the LDS budget (5 x 5 with 96 columns)
+            assert cfg >= 0 and 'rc=-2' in str(e), e
+    torch.cuda.synchronize()
+    assert len(outs) >= 3
+    for y in outs[1:]:
+        assert torch.equal(y, outs[0])
+    xin = torch.from_numpy(x).double()
+    ref = O.conv2d(O.relu(xin) if relu else xin, torch.from_numpy(k).double(), (1, 1), 'same')
+    ref = ref * torch.from_numpy(qs).double() + torch.from_numpy(qb).double()
+    if res:
+        ref = ref + torch.from_numpy(r1).double()
+    _close(outs[0], torch.relu(ref), atol=5e-5, what='halo conv %s' % (case,))
+    # frames are independent: the last frame alone gives the same bits
+    one = F.conv2d(d(x[-1:]), k, halo=True, **dict(kw_, res1=d(None if r1 is None else r1[-1:])))
+    assert torch.equal(one, outs[0][-1:])
+    # the tap-major kernels agree to fp32 rounding (different K order: not the same bits)
+    tap = F.conv2d(d(x), k, **kw_)
+    assert float((tap - outs[0]).abs().max()) < 5e-5
+    a = _lib.ConvArgs()
+    a.x = 4096
+    a.N, a.H, a.W, a.Cin, a.ldx, a.OH, a.OW, a.Cout, a.ldy = n, h, w, cin, cin, h, w, cout, cout
+    a.KH, a.KW, a.SH, a.SW, a.PT, a.PL, a.K = kh, kw, 1, 1, (kh - 1) // 2, (kw - 1) // 2, kh * kw * cin
+    want = int(cin % 32 != 0)                    # the binding rule: only what the tap-major DMA kernel cannot take
+    assert hip_lib.dh_conv2d_halo_eligible(C.byref(a)) == want
+    a.N = 1                                      # the rule never looks at the batch size
+    assert hip_lib.dh_conv2d_halo_eligible(C.byref(a)) == want
+    a.SH = a.SW = 2
+    assert hip_lib.dh_conv2d_halo_eligible(C.byref(a)) == 0
+
+
+@pytest.mark.gpu
+def test_conv2d_halo_rejects_other_layers(hip_lib, cuda):
+    """w_split = 2 on a layer outside the rule is refused (DH_EUNSUPPORTED), never run on another kernel."""
+    from deephar_amd import functional as F
+    rng = np.random.default_rng(3)
+    d = lambda a: torch.from_numpy(a).to(cuda)
+    for shape, k, strides in (((1, 16, 16, 32), (3, 3, 32, 32), (1, 1)),       # small map
+                              ((1, 64, 64, 32), (3, 3, 32, 32), (2, 2)),       # strided
+                              ((1, 64, 64, 32), (1, 1, 32, 32), (1, 1)),       # pointwise
+                              ((1, 64, 48, 32), (3, 3, 32, 32), (1, 1))):      # rows that do not tile into 128 pixels
+        with pytest.raises(Exception) as e:
+            F.conv2d(d(_rand(rng, shape)), _rand(rng, k), strides, halo=True)
+        assert 'rc=-2' in str(e.value), e.value
+    with pytest.raises(ValueError):
+        F.conv2d(d(_rand(rng, (1, 64, 64, 24))), _rand(rng, (3, 3, 24, 32)), halo=True)     # Cin % 16 != 0: no such packing
+
+
 # ---- split-bf16 GEMM (dh_conv_args.w_split, gemm1x1s.hip) --------------------------------------------------------------
 SPLIT_CASES = [
     # (N, H, W, Cin, Cout, k, stride, relu, residual, up2)
