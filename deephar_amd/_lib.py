@@ -74,6 +74,15 @@ SIGNATURES = {
     'dh_copy_channels_f32': (C.c_int, [vp, C.c_int, vp, C.c_int, i64, C.c_int, vp]),
     'dh_zeropad2d_f32': (C.c_int, [vp, vp] + [C.c_int] * 8 + [vp]),
     'dh_depth_from_maps_f32': (C.c_int, [vp, C.c_int, vp, C.c_int, vp, C.c_int] + [C.c_int] * 3 + [vp]),
+    'dh_plan_create': (C.c_int, [vp, C.c_size_t, C.POINTER(vp)]),
+    'dh_plan_destroy': (C.c_int, [vp]),
+    'dh_plan_batch': (C.c_int, [vp]),
+    'dh_plan_num_inputs': (C.c_int, [vp]),
+    'dh_plan_num_outputs': (C.c_int, [vp]),
+    'dh_plan_input_items': (C.c_int64, [vp, C.c_int]),
+    'dh_plan_output_items': (C.c_int64, [vp, C.c_int]),
+    'dh_forward': (C.c_int, [vp, C.POINTER(vp), C.c_int, C.POINTER(vp), vp]),
+    'dh_forward_host': (C.c_int, [vp, C.POINTER(vp), C.c_int, C.POINTER(vp)]),
     'dh_graph_begin_capture': (C.c_int, [vp]),
     'dh_graph_end_capture': (C.c_int, [vp, C.POINTER(vp)]),
     'dh_graph_launch': (C.c_int, [vp, vp]),

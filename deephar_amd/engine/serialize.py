@@ -1,0 +1,121 @@
+"""Serialise a bound plan for the C-level executor of the library (include/deephar_hip.h: dh_plan_create / dh_forward /
+dh_plan_destroy -- SURVEY.md 8b's plan / execute pair): a host written in C or C++ runs the model without Python.
+
+Blob (little endian):
+    header   'DHPL' u32 version | i32 batch n | u64 arena bytes | u64 weight bytes | u32 #inputs | u32 #outputs | u32 #steps
+    inputs   per input : u64 arena byte offset | u64 floats per batch item
+    outputs  per output: u64 arena byte offset | u64 pixels per batch item | u32 channels | u32 pixel pitch (floats)
+    steps    per launch: u32 function id | u32 payload bytes | payload
+               struct functions: the argument struct, byte for byte (+ i32 tile_cfg for dh_conv2d_f32)
+               scalar functions: one u64 per argument (ints sign-extended, floats as their bit pattern)
+             every device pointer (struct field or scalar) is written as 0 (NULL) or (region << 60) | byte offset,
+             region 1 = the activation arena, 2 = the weight image
+    weights  the weight image (packed conv / depthwise kernels, BN affines, grids), every tensor 256-byte aligned
+Launch order is the plan's step order, a valid single-stream schedule of the graph; tilings are the bound plan's
+(autotuned) ones, so dh_forward reproduces Model.predict bit for bit.
+"""
+import ctypes as C
+import struct
+
+import numpy as np
+
+from .. import _lib
+
+MAGIC, VERSION = b'DHPL', 1
+FUNCTIONS = ['dh_conv2d_f32', 'dh_dwconv2d_f32', 'dh_pool2d_f32', 'dh_upsample2x_add_f32', 'dh_eltwise_f32',
+             'dh_softargmax2d_f32', 'dh_context_aggregation_f32', 'dh_depth_means_f32', 'dh_softargmax1d_f32',
+             'dh_kronecker_f32', 'dh_global_maxmin_softmax_f32', 'dh_copy_channels_f32', 'dh_zeropad2d_f32',
+             'dh_depth_from_maps_f32']
+ARENA, WEIGHTS = 1, 2
+
+
+class _Regions:
+    def __init__(self, bp):
+        self.base = bp.base
+        self.end = bp.base + bp.arena.numel() * 4
+        st = bp.store
+        tensors = [e[0] for e in st.conv.values()] + [e[0] for e in st.dw.values()] + list(st.const.values())
+        for e in st.bn.values():
+            tensors += [e[0], e[1]]
+        self.known = sorted(((t.data_ptr(), t.data_ptr() + t.numel() * t.element_size(), t) for t in tensors),
+                            key=lambda r: r[0])
+        self.offset = {}          # tensor data_ptr -> byte offset in the weight image
+        self.image = []
+        self.size = 0
+
+    def tag(self, ptr):
+        ptr = int(ptr or 0)
+        if ptr == 0:
+            return 0
+        if self.base <= ptr < self.end:
+            return (ARENA << 60) | (ptr - self.base)
+        for lo, hi, t in self.known:
+            if lo <= ptr < hi:
+                if lo not in self.offset:
+                    self.size = (self.size + 255) & ~255
+                    self.offset[lo] = self.size
+                    self.image.append((self.size, t))
+                    self.size += hi - lo
+                return (WEIGHTS << 60) | (self.offset[lo] + ptr - lo)
+        raise ValueError('pointer 0x%x belongs neither to the arena nor to the weight store' % ptr)
+
+
+def _is_ptr_type(t):
+    return t is C.c_void_p
+
+
+def dump_plan(model, batch):
+    """-> bytes.  `model`'s plan bound (and autotuned) for `batch`; needs a HIP device (the weight image is read back)."""
+    ex = model.executor
+    torch = __import__('torch')
+    with torch.cuda.device(ex.device), torch.cuda.stream(ex.stream):
+        if ex.bound:
+            ex.sync_weights()
+        bp = ex.bind(batch)
+    ex.stream.synchronize()
+    if bp.u8 is not None or bp.npre:
+        raise ValueError('only float-input plans are serialised')
+    lib = _lib.load()
+    names = {n: i for i, n in enumerate(FUNCTIONS)}
+    by_addr = {C.cast(getattr(lib, n), C.c_void_p).value: n for n in FUNCTIONS}
+    reg = _Regions(bp)
+    steps = []
+    for fn, args, step in bp.calls:
+        name = by_addr.get(C.cast(fn, C.c_void_p).value)
+        if name is None:
+            raise ValueError('step %s (%s) has no serialised form' % (step.kind, step.name))
+        sig = _lib.SIGNATURES[name][1][:-1]                 # without the trailing stream
+        if len(sig) and isinstance(getattr(sig[0], '_type_', None), type) and issubclass(sig[0]._type_, C.Structure):
+            obj = args[0]._obj
+            raw = bytearray(bytes(obj))
+            for fname, ftype in obj._fields_:
+                if _is_ptr_type(ftype):
+                    off = getattr(type(obj), fname).offset
+                    raw[off:off + 8] = struct.pack('<Q', reg.tag(getattr(obj, fname)))
+            payload = bytes(raw) + b''.join(struct.pack('<i', int(a)) for a in args[1:])
+        else:
+            assert len(sig) == len(args), (name, len(sig), len(args))
+            parts = []
+            for t, a in zip(sig, args):
+                if _is_ptr_type(t):
+                    parts.append(struct.pack('<Q', reg.tag(a)))
+                elif t is C.c_float:
+                    parts.append(struct.pack('<fI', float(a), 0))
+                else:
+                    parts.append(struct.pack('<q', int(a)))
+            payload = b''.join(parts)
+        steps.append(struct.pack('<II', names[name], len(payload)) + payload)
+    plan = bp.plan
+    head = MAGIC + struct.pack('<IiQQIII', VERSION, bp.n, bp.arena.numel() * 4, (reg.size + 255) & ~255,
+                               len(plan.inputs), len(plan.outputs), len(steps))
+    ins = b''.join(struct.pack('<QQ', bp.ptr(v) - bp.base, int(np.prod(v.shape))) for v in plan.inputs)
+    outs = b''
+    for v in plan.outputs:
+        if v.coff % 1 or v.ld < v.C:
+            raise ValueError('output view not serialisable')
+        outs += struct.pack('<QQII', bp.ptr(v) - bp.base, v.npix, v.C, v.ld)
+    image = bytearray((reg.size + 255) & ~255)
+    for off, t in reg.image:
+        b = t.detach().cpu().contiguous().numpy().tobytes()
+        image[off:off + len(b)] = b
+    return head + ins + outs + b''.join(steps) + bytes(image)

@@ -167,6 +167,16 @@ class Model:
         from . import weights as W
         W.save_weights(self, filepath)
 
+    def export_plan(self, filepath, batch_size):
+        """Write the bound, autotuned launch list + weight image of this model for `batch_size` items: the blob the
+        C-level executor of the library runs without Python (dh_plan_create / dh_forward, include/deephar_hip.h;
+        INTEGRATION.md shows a C host).  Returns the number of bytes written."""
+        from .engine.serialize import dump_plan
+        blob = dump_plan(self, int(batch_size))
+        with open(filepath, 'wb') as f:
+            f.write(blob)
+        return len(blob)
+
     # ---- execution -----------------------------------------------------------------------------------------
     @property
     def plan(self):

@@ -226,6 +226,31 @@ int dh_depth_from_maps_f32(const float* d, int ldd, const float* h, int ldh, flo
                            int J, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------
+ * Plan / execute pair: a whole model forward behind three calls, for hosts without Python (what a C or
+ * C++ replacement of Keras' Model.predict -- exp/common/mpii_tools.py:25,86, h36m_tools.py:46, penn_tools.py:124 -- binds).
+ *   blob   : written by deephar_amd.Model.export_plan(path, batch) (deephar_amd/engine/serialize.py): the bound,
+ *            autotuned launch list of Model.predict for `batch` items, device pointers relative to the activation
+ *            arena / the weight image, plus the weight image itself (packed kernels, BN affines, grids).
+ *   create : allocates arena + weights on the current device, uploads the weights, patches the pointers.  One plan
+ *            per device; a plan is not re-entrant (one forward at a time), different plans are independent.
+ *   forward: m <= batch items; inputs[i] / outputs[i] are DEVICE pointers to dense float32 [m, ...] tensors in the
+ *            model's input / output order (outputs[i] may be NULL: not wanted); everything is enqueued on `stream`,
+ *            nothing synchronises.  Results are bit-identical to Model.predict of the exporting process.
+ *   forward_host: the same with HOST pointers (H2D, forward, D2H on an internal stream; returns when done).
+ * Float inputs only (uint8 plans are not serialised).  rc != 0 -> the host raises its own error.
+ * ------------------------------------------------------------------------------------------------- */
+typedef struct dh_plan dh_plan;
+int dh_plan_create(const void* blob, size_t blob_bytes, dh_plan** plan_out);
+int dh_plan_destroy(dh_plan* plan);
+int dh_plan_batch(const dh_plan* plan);
+int dh_plan_num_inputs(const dh_plan* plan);
+int dh_plan_num_outputs(const dh_plan* plan);
+int64_t dh_plan_input_items(const dh_plan* plan, int i);  /* floats per batch item of input i */
+int64_t dh_plan_output_items(const dh_plan* plan, int i); /* floats per batch item of output i */
+int dh_forward(dh_plan* plan, const float* const* inputs_dev, int m, float* const* outputs_dev, void* stream);
+int dh_forward_host(dh_plan* plan, const float* const* inputs_host, int m, float* const* outputs_host);
+
+/* ---------------------------------------------------------------------------------------------------
  * Stream-ordered runtime helpers (no torch types): graphs for launch-bound replay, events for timing.
  * ------------------------------------------------------------------------------------------------- */
 int dh_graph_begin_capture(void* stream);

@@ -1,0 +1,101 @@
+"""SURVEY.md 8b's plan / execute pair: Model.export_plan -> dh_plan_create / dh_forward / dh_forward_host /
+dh_plan_destroy.  The C-level executor replays the bound, autotuned launch list on its own arena and weight image;
+results must be the bits Model.predict returns.  Also a host with no Python in it: tools/c_host/predict_plan.c,
+compiled with gcc against include/deephar_hip.h, run as a separate process."""
+import ctypes as C
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _plan(lib, blob):
+    h = C.c_void_p()
+    rc = lib.dh_plan_create(blob, len(blob), C.byref(h))
+    assert rc == 0, rc
+    return h
+
+
+@pytest.mark.parametrize('kind', ['reception2d', 'reception3d', 'merge'])
+def test_c_plan_reproduces_predict_bit_for_bit(kind, hip_lib, cuda, tmp_path):
+    from test_gpu_models import _build, _merge
+    rng = np.random.default_rng(17)
+    if kind == 'reception2d':
+        m, _ = _build(2, 2, 16, num_context_per_joint=2, concat_pose_confidence=False)
+        x = rng.uniform(-1, 1, (5, 256, 256, 3)).astype(np.float32)
+    elif kind == 'reception3d':
+        m, _ = _build(3, 2, 17, depth_maps=16)
+        x = rng.uniform(-1, 1, (5, 256, 256, 3)).astype(np.float32)
+    else:
+        m, _ = _merge(2, 4, 16, 2, num_actions=15)
+        x = rng.uniform(-1, 1, (3, 4, 256, 256, 3)).astype(np.float32)
+    n = len(x)
+    ref = m.predict(x, batch_size=n)
+    ref = ref if isinstance(ref, list) else [ref]
+    path = str(tmp_path / 'model.dhplan')
+    nbytes = m.export_plan(path, n)
+    blob = open(path, 'rb').read()
+    assert len(blob) == nbytes and blob[:4] == b'DHPL'
+    plan = _plan(hip_lib, blob)
+    try:
+        assert hip_lib.dh_plan_batch(plan) == n and hip_lib.dh_plan_num_inputs(plan) == 1
+        assert hip_lib.dh_plan_num_outputs(plan) == len(ref)
+        assert hip_lib.dh_plan_input_items(plan, 0) == x[0].size
+        assert [hip_lib.dh_plan_output_items(plan, k) for k in range(len(ref))] == [r[0].size for r in ref]
+        # device pointers, caller's stream
+        xd = torch.from_numpy(x).to(cuda)
+        outs = [torch.full(r.shape, float('nan'), device=cuda) for r in ref]
+        ins_p = (C.c_void_p * 1)(xd.data_ptr())
+        outs_p = (C.c_void_p * len(outs))(*[o.data_ptr() for o in outs])
+        st = torch.cuda.current_stream().cuda_stream
+        assert hip_lib.dh_forward(plan, ins_p, n, outs_p, st) == 0
+        torch.cuda.synchronize()
+        for o, r in zip(outs, ref):
+            assert np.array_equal(o.cpu().numpy(), r)
+        # fewer items than the plan was bound for; host pointers
+        mrows = n - 2
+        host = [np.full((mrows,) + r.shape[1:], np.nan, np.float32) for r in ref]
+        xin = np.ascontiguousarray(x[:mrows])
+        ins_h = (C.c_void_p * 1)(xin.ctypes.data)
+        outs_h = (C.c_void_p * len(host))(*[h.ctypes.data for h in host])
+        assert hip_lib.dh_forward_host(plan, ins_h, mrows, outs_h) == 0
+        for h, r in zip(host, ref):
+            assert np.array_equal(h, r[:mrows])
+        assert hip_lib.dh_forward_host(plan, ins_h, n + 1, outs_h) != 0          # more items than the plan holds
+    finally:
+        assert hip_lib.dh_plan_destroy(plan) == 0
+    # malformed blobs are refused, not executed
+    h = C.c_void_p()
+    assert hip_lib.dh_plan_create(blob[:100], 100, C.byref(h)) != 0
+    assert hip_lib.dh_plan_create(b'XXXX' + blob[4:], len(blob), C.byref(h)) != 0
+    assert hip_lib.dh_plan_create(blob[:-16], len(blob) - 16, C.byref(h)) != 0
+
+
+def test_pure_c_host_runs_an_exported_plan(hip_lib, cuda, tmp_path):
+    """gcc-compiled host (no Python, no HIP headers): plan file + raw frames in, raw outputs out, equal to predict."""
+    from test_gpu_models import _build
+    m, _ = _build(2, 2, 16, num_context_per_joint=2, concat_pose_confidence=True)
+    x = np.random.default_rng(18).uniform(-1, 1, (4, 256, 256, 3)).astype(np.float32)
+    ref = m.predict(x, batch_size=4)
+    m.export_plan(str(tmp_path / 'm.dhplan'), 4)
+    x.tofile(str(tmp_path / 'x.f32'))
+    exe = str(tmp_path / 'predict_plan')
+    libdir = os.path.join(ROOT, 'deephar_amd', 'csrc')
+    r = subprocess.run(['gcc', '-O2', '-I' + os.path.join(ROOT, 'include'),
+                        os.path.join(ROOT, 'tools', 'c_host', 'predict_plan.c'), '-L' + libdir, '-ldeephar_hip',
+                        '-Wl,-rpath,' + libdir, '-o', exe], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    r = subprocess.run([exe, str(tmp_path / 'm.dhplan'), str(tmp_path / 'x.f32'), str(tmp_path / 'out')],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    print(r.stdout.strip())
+    for k, want in enumerate(ref):
+        got = np.fromfile(str(tmp_path / ('out.%d.f32' % k)), np.float32).reshape(want.shape)
+        assert np.array_equal(got, want), k
