@@ -55,6 +55,21 @@ class Model:
             for o in n.outputs:
                 reach.add(o.uid)
 
+    # ---- engine options: changing one after the first predict re-plans (plan, bound arenas and graphs are dropped) ---
+    def _engine_option(name):                  # noqa: N805  (class-body helper)
+        def get(self):
+            return self.__dict__['_opt_' + name]
+
+        def set_(self, value):
+            if self.__dict__.get('_opt_' + name, value) != value and self.__dict__.get('_plan') is not None:
+                self._plan, self._exec = None, None
+            self.__dict__['_opt_' + name] = value
+        return property(get, set_)
+
+    gemm_precision = _engine_option('gemm_precision')
+    num_streams = _engine_option('num_streams')
+    del _engine_option
+
     # ---- Keras-like attributes -----------------------------------------------------------------------
     @property
     def input(self):

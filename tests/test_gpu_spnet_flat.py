@@ -77,8 +77,10 @@ def _flat_checks(tag, hip, o32, o64, dim, npose, case):
 def test_spnet_flat_1e3_px(name, mode, hip_lib, cuda):
     from deephar_amd.models import spnet
     m, x, ocfg, o32, o64, stats, (pyr, apyr) = _prepare(name)
-    m.gemm_precision = mode
+    m.gemm_precision = mode                          # (an engine option: changing it re-plans the model)
     hip = m.predict(x, batch_size=1)
+    nsplit = sum(1 for s in m.plan.steps if s.kind == 'conv' and s.attrs.get('w_split') == 1)
+    assert (nsplit > 20) == (mode == 'bf16x3'), (mode, nsplit)          # the mode under test is the mode that ran
     npose = spnet.get_num_predictions(pyr, 4)
     assert len(hip) == npose + spnet.get_num_predictions(len(apyr), 4)
     assert [h.shape for h in hip] == [o.shape for o in o64]

@@ -315,6 +315,22 @@ def test_split_k_rule_matches_the_library(hip_lib):
     assert n > 500
 
 
+def test_engine_options_replan_the_model():
+    """Model.gemm_precision / num_streams set AFTER the plan exists take effect at the next predict: plan and executor
+    are dropped (a silently ignored option once made a bf16x3 parity test run in fp32)."""
+    m = _mpii(1)
+    p1 = m.plan
+    assert p1.gemm_precision == 'f32'
+    m.gemm_precision = 'f32'
+    assert m.plan is p1                                  # unchanged value: nothing is thrown away
+    m.gemm_precision = 'bf16x3'
+    assert m._plan is None and m._exec is None
+    p2 = m.plan
+    assert p2 is not p1 and p2.gemm_precision == 'bf16x3'
+    m.num_streams = 1
+    assert m._plan is None and m.plan.nstreams == 1
+
+
 def test_split_eligibility_is_the_librarys_answer(hip_lib):
     """dh_conv2d_split_eligible (asked by the executor before it packs a layer's weights for bf16x3 mode):
     LDS-DMA GEMM shapes with an aligned float input and no BN prologue, not split-K layers, and -- what the Python
