@@ -106,6 +106,7 @@ int dh_conv2d_f32(const dh_conv_args* a, int tile_cfg, void* stream) {
   if ((a->pre_scale == nullptr) != (a->pre_shift == nullptr)) return DH_EINVAL;
   if ((a->post_scale == nullptr) != (a->post_shift == nullptr)) return DH_EINVAL;
   if (a->SH <= 0 || a->SW <= 0 || a->KH <= 0 || a->KW <= 0) return DH_EINVAL;
+  if (a->res2_down && (a->res2 == nullptr || a->up2 || (a->OH & 1) || (a->OW & 1))) return DH_EINVAL;
   return launch_conv_igemm(*a, tile_cfg, S(stream));
 }
 

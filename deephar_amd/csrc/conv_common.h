@@ -30,7 +30,8 @@ __device__ __forceinline__ int xcd_tile(int b, int nwg) {
 // Epilogue.  C/D layout of a 32x32 MFMA tile: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).
 // Each wave stages one 32 x (TN*32) row block through its private LDS slab and reads it back row-wise, so
 // the BN affine / residual loads / stores are 16-byte wide and whole output rows are contiguous.
-//   out = relu?( acc*post_scale + post_shift + res1[m] + res2[mo] ), optionally written 2x up-sampled.
+//   out = relu?( acc*post_scale + post_shift + res1[m] + res2[mo] ), optionally written 2x up-sampled, or with
+//   res2 read at half resolution (res2_down: the UpSampling2D sits on the residual instead of on the result).
 //
 // The epilogue is latency-, not bandwidth-bound: a work-group that loads its residual tile only after the last
 // MFMA sits through one HBM round trip per dependent batch while the other work-groups of the CU -- started
@@ -96,6 +97,8 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x16 (&acc)[T
   float* sC = smem + wave * 32 * LDC;
   const int ohw = p.OH * p.OW;
   const bool vec = epi_vec != 0;
+  const bool pow2 = (p.OW & (p.OW - 1)) == 0 && (ohw & (ohw - 1)) == 0;      // (uniform) maps of 2^a x 2^b pixels: shifts
+  const int ow_sh = __ffs(p.OW) - 1, ohw_sh = __ffs(ohw) - 1;
   __syncthreads();                            // every wave is done with the operand stages
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
@@ -147,9 +150,18 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x16 (&acc)[T
           const int m = m0 + (wm * TM + i) * 32 + row;
           const int mc = m < M ? m : M - 1;
           if constexpr (UP2) {
-            const int fr = mc / ohw;
-            const int rem = mc - fr * ohw;
-            const int oh = rem / p.OW, ow = rem - oh * p.OW;
+            int fr, oh, ow;
+            if (pow2) {
+              fr = mc >> ohw_sh;
+              const int rem = mc & (ohw - 1);
+              oh = rem >> ow_sh;
+              ow = rem & (p.OW - 1);
+            } else {
+              fr = mc / ohw;
+              const int rem = mc - fr * ohw;
+              oh = rem / p.OW;
+              ow = rem - oh * p.OW;
+            }
 #pragma unroll
             for (int d = 0; d < 4; ++d)
               mo[u][d] = ((size_t)fr * 2 * p.OH + 2 * oh + (d >> 1)) * (2 * p.OW) + 2 * ow + (d & 1);
@@ -157,9 +169,28 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x16 (&acc)[T
             mo[u][0] = (size_t)mc;
           }
           if (p.res2 != nullptr) {
+            if (!UP2 && p.res2_down) {
+              // res2 lives at HALF resolution: out(oh, ow) += res2(oh / 2, ow / 2) = add([., UpSampling2D(res2)]); the four
+              // pixels that share a source row hit it in L2 (rows of a tile are consecutive pixels)
+              int fr, oh, ow;
+              if (pow2) {                                    // no integer divide on this hardware: ~40 VALU each, and the
+                fr = mc >> ohw_sh;                           // epilogue's VALU is paid in full beside the other waves' MFMAs
+                const int rem = mc & (ohw - 1);
+                oh = rem >> ow_sh;
+                ow = rem & (p.OW - 1);
+              } else {
+                fr = mc / ohw;
+                const int rem = mc - fr * ohw;
+                oh = rem / p.OW;
+                ow = rem - oh * p.OW;
+              }
+              const size_t mr = ((size_t)fr * (p.OH >> 1) + (oh >> 1)) * (p.OW >> 1) + (ow >> 1);
+              r2[u][0] = *reinterpret_cast<const float4*>(p.res2 + mr * p.ldr2 + ncol[it % NSC]);
+            } else {
 #pragma unroll
-            for (int d = 0; d < ND; ++d)
-              r2[u][d] = ld4_stream(p.res2 + mo[u][d] * p.ldr2 + ncol[it % NSC]);
+              for (int d = 0; d < ND; ++d)
+                r2[u][d] = ld4_stream(p.res2 + mo[u][d] * p.ldr2 + ncol[it % NSC]);
+            }
           }
         }
         // combine + store
@@ -220,7 +251,16 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x16 (&acc)[T
           if (p.res1 != nullptr) t += p.res1[(size_t)m * p.ldr1 + n + e];
           for (int d = 0; d < nout; ++d) {
             float o = t;
-            if (p.res2 != nullptr) o += p.res2[mo[d] * p.ldr2 + n + e];
+            if (p.res2 != nullptr) {
+              size_t mr = mo[d];
+              if (!UP2 && p.res2_down) {
+                const int fr = m / ohw;
+                const int rem = m - fr * ohw;
+                const int oh = rem / p.OW, ow = rem - oh * p.OW;
+                mr = ((size_t)fr * (p.OH >> 1) + (oh >> 1)) * (p.OW >> 1) + (ow >> 1);
+              }
+              o += p.res2[mr * p.ldr2 + n + e];
+            }
             if (p.post_relu) o = fmaxf(o, 0.f);
             p.y[mo[d] * p.ldy + n + e] = o;
           }

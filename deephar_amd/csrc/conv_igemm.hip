@@ -310,7 +310,10 @@ int launch_conv_igemm(const ConvArgs& a, int cfg, hipStream_t s) {
   if (a.x_u8 && a.in_lut == nullptr) return DH_EINVAL;
   // tiny output, long reduction: the in-work-group split-K kernel, whatever tiling was asked for (shape rule: the
   // result bits of a layer must not depend on a timing-based choice)
-  if (conv_is_skinny(a)) return cfg < kNumCfgs + gemm1x1_num_cfgs() ? launch_conv_splitk(a, s) : DH_EINVAL;
+  if (conv_is_skinny(a)) {
+    if (a.res2_down) return DH_EUNSUPPORTED;          // (the split-K kernel has its own, simpler epilogue)
+    return cfg < kNumCfgs + gemm1x1_num_cfgs() ? launch_conv_splitk(a, s) : DH_EINVAL;
+  }
   auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
   const int epi = (a.Cout % 4 == 0) && (a.ldy % 4 == 0) && al16(a.y) &&
                   (a.res1 == nullptr || (a.ldr1 % 4 == 0 && al16(a.res1))) &&

@@ -9,8 +9,11 @@ Fusion rules (what the reference leaves to TensorFlow as separate kernels):
                 the conv input (layers.py:258-301 "act_conv_bn", common.py:40-54); never materialised.
   R2 epilogue : conv -> BN -> ReLU -> add chains with a single consumer are applied on the accumulator
                 (layers.py:202-241, reception.py:57,312).
-  R3 upsample : conv -> UpSampling2D -> add (reception.py:122-127) is written by the conv epilogue at 2x
-                resolution; a free-standing UpSampling2D -> add becomes one upsample_add kernel.
+  R3 upsample : add([a, UpSampling2D(b)]) (reception.py:122-127) is folded into the convolution that produces `a`, which
+                reads `b` at half resolution as its second residual (dh_conv_args.res2_down); that convolution is
+                emitted once `b` exists (the low-resolution branch goes first).  Saves writing `a` and reading it
+                back.  Where `a` has no free residual slot: conv -> UpSampling2D -> add is written by the conv
+                epilogue at 2x resolution; a free-standing UpSampling2D -> add becomes one upsample_add kernel.
   R4 concat   : producers write straight into the concatenation buffer at their channel offset
                 (reception.py:75,83,87); Lambda channel slices are pointer/ld views (reception.py:171-172).
   R5 decoder  : channel soft-max + both lin_interpolation_2d + joint confidence (+ global max) on the same
@@ -145,6 +148,7 @@ class Planner:
             self.out_uids[t.uid] = self.out_uids.get(t.uid, 0) + 1
         self.concat_val = {}   # concat node uid -> Value
         self.processed = set()
+        self.deferred = {}     # tensor uid a deferred conv node waits for -> [node]   (R3)
 
     # ---- helpers ------------------------------------------------------------------------------------
     def new_buf(self, shape, kind='act'):
@@ -226,8 +230,12 @@ class Planner:
         for node in self.nodes:
             if node.uid in self.absorbed:
                 continue
+            if node.op in ('conv', 'sepconv') and self._defer_for_upsampled_residual(node):
+                continue
             getattr(self, 'op_' + node.op)(node)
             self.processed.add(node.uid)
+            self._flush_deferred()
+        assert not self.deferred, 'deferred convolutions never became ready'
         for t in self.g_outputs:
             v = self.materialize(t)
             v.buf.pinned = True
@@ -236,6 +244,68 @@ class Planner:
         from . import schedule
         schedule.finalize(self.plan, self.nstreams)
         return self.plan
+
+    # ---- R3: add([a, UpSampling2D(b)]) as the second residual of the convolution that produces a --------------
+    def _upsampled_residual(self, t):
+        """t = a convolution's output after its own BN / first residual add.  -> (add node, upsample node, b) when t's
+        only consumer is add([t, UpSampling2D(b)]) with b at half resolution and the same channels, else None."""
+        a2 = self.sole_consumer(t, 'add')
+        if a2 is None or len(a2.inputs) != 2 or len(t.shape) < 3 or os.environ.get('DEEPHAR_RES2_DOWN', '1') == '0':
+            return None                          # (the switch exists for A/B measurements of the rule)
+        other = [x for x in a2.inputs if x.uid != t.uid]
+        if len(other) != 1:
+            return None
+        up = next((n for n in self.nodes if n.op == 'upsample' and n.outputs[0].uid == other[0].uid), None)
+        if up is None or self.sole_consumer(up.outputs[0], 'add') is not a2:
+            return None
+        b = up.inputs[0]
+        if tuple(b.shape[:-3]) != tuple(t.shape[:-3]) or b.shape[-1] != t.shape[-1] or t.shape[-3] % 2 or \
+                t.shape[-2] % 2 or (b.shape[-3], b.shape[-2]) != (t.shape[-3] // 2, t.shape[-2] // 2):
+            return None
+        return a2, up, b
+
+    def _epilogue_tail(self, out_t):
+        """Side-effect free walk conv -> bn -> (add with ONE available other) like _epilogue; -> (the tensor after it, the
+        nodes walked over), tensor None when a ReLU or a two-residual add makes the second residual slot unavailable."""
+        t, chain = out_t, []
+        n = self.sole_consumer(t, 'bn')
+        if n is not None:
+            t = n.outputs[0]
+            chain.append(n)
+        if self.sole_consumer(t, 'relu') is not None:
+            return None, chain
+        n = self.sole_consumer(t, 'add')
+        if n is not None:
+            others = [x for x in n.inputs if x.uid != t.uid]
+            if len(others) == len(n.inputs) - 1 and len(others) == 1 and all(self.available(x) for x in others):
+                return n.outputs[0], chain + [n]
+            if self._upsampled_residual(t) is None:
+                return None, chain
+        return t, chain
+
+    def _defer_for_upsampled_residual(self, node):
+        """True (and the node is parked) when this convolution can take add([., UpSampling2D(b)]) as its second residual
+        but b does not exist yet: it is emitted right after the step that produces b."""
+        if not all(self.available(x) for x in node.inputs):
+            return False
+        t, chain = self._epilogue_tail(node.outputs[0])
+        hit = self._upsampled_residual(t) if t is not None else None
+        if hit is None or self.available(hit[2]):
+            return False
+        self.deferred.setdefault(hit[2].uid, []).append(node)
+        # the epilogue chain (absorbed again, for good, when the convolution is emitted) and the UpSampling2D / add pair
+        # must not run on their own in the meantime
+        self.absorbed.update(n.uid for n in chain + [hit[0], hit[1]])
+        return True
+
+    def _flush_deferred(self):
+        ready = [uid for uid in self.deferred if uid in self.val]
+        while ready:
+            for uid in ready:
+                for node in self.deferred.pop(uid):
+                    getattr(self, 'op_' + node.op)(node)
+                    self.processed.add(node.uid)
+            ready = [uid for uid in self.deferred if uid in self.val]
 
     # ---- element-wise laziness (R1) --------------------------------------------------------------------
     def op_bn(self, node):
@@ -263,7 +333,7 @@ class Planner:
 
     def _epilogue(self, out_t):
         """Walk conv -> bn -> relu -> add -> (upsample -> add) while each link has a single consumer."""
-        epi = dict(post_bn=None, post_relu=False, res1=None, res2=None, up2=False)
+        epi = dict(post_bn=None, post_relu=False, res1=None, res2=None, up2=False, res2_down=False)
         t = out_t
         n = self.sole_consumer(t, 'bn')
         if n is not None:
@@ -288,6 +358,14 @@ class Planner:
                     self.absorbed.add(n.uid)
                     t = n.outputs[0]
             if epi['res2'] is None:
+                hit = self._upsampled_residual(t)
+                if hit is not None and self.available(hit[2]):
+                    a2, up, b = hit
+                    epi['res2'] = self.materialize(b)
+                    epi['res2_down'] = True
+                    self.absorbed.update((a2.uid, up.uid))
+                    t = a2.outputs[0]
+            if epi['res2'] is None:
                 u = self.sole_consumer(t, 'upsample')
                 if u is not None and len(t.shape) >= 3:
                     a = self.sole_consumer(u.outputs[0], 'add')
@@ -306,7 +384,7 @@ class Planner:
         y = self.out_value_for(final_t)
         attrs = dict(kh=a['kh'], kw=a['kw'], sh=a.get('sh', 1), sw=a.get('sw', 1), pt=a['pt'], pl=a['pl'],
                      Cin=x.C, Cout=a['filters'], K=a['kh'] * a['kw'] * x.C, pre_relu=int(pre_relu),
-                     post_relu=int(epi['post_relu']), up2=int(epi['up2']))
+                     post_relu=int(epi['post_relu']), up2=int(epi['up2']), res2_down=int(epi['res2_down']))
         ins = dict(x=x)
         if epi['res1'] is not None:
             ins['res1'] = epi['res1']

@@ -45,7 +45,7 @@ def pack_conv_weight(w_hwio, device='cuda'):
 
 def conv2d(x, w_hwio, strides=(1, 1), padding='same', pre_scale=None, pre_shift=None, pre_relu=False,
            post_scale=None, post_shift=None, post_relu=False, res1=None, res2=None, up2=False, tile_cfg=-1,
-           packed=None, in_lut=None, split=False, halo=False):
+           packed=None, in_lut=None, split=False, halo=False, res2_down=False):
     """Fused conv (see dh_conv2d_f32).  x [N,H,W,Cin]; w_hwio numpy [kh,kw,Cin,Cout].  A uint8 `x` needs
     `in_lut` (float32 [Cin,256] device tensor, engine.executor.normalization_lut): bytes are normalised on load."""
     torch = _t()
@@ -88,6 +88,7 @@ def conv2d(x, w_hwio, strides=(1, 1), padding='same', pre_scale=None, pre_shift=
     a.ldr1 = res1.shape[-1] if res1 is not None else 0
     a.ldr2 = res2.shape[-1] if res2 is not None else 0
     a.pre_relu, a.post_relu, a.up2 = int(pre_relu), int(post_relu), int(up2)
+    a.res2_down = int(res2_down)
     if x.dtype == torch.uint8:
         a.in_lut, a.x_u8 = _p(in_lut), 1
     _lib.check(lib.dh_conv2d_f32(C.byref(a), tile_cfg, _stream()), 'dh_conv2d_f32')

@@ -35,9 +35,12 @@ class Model:
         self.trainable = True
         self._plan = None
         self._exec = None
-        # independent branches run on parallel hipGraph branches (engine/schedule.py); measured on the MPII model:
-        # 2 streams +1..8 % over one, 3 and 4 streams 2-3 % SLOWER than 2 (chip-filling kernels only contend)
-        self.num_streams = max(1, int(__import__('os').environ.get('DEEPHAR_STREAMS', '2')))
+        # >1: independent branches run on parallel hipGraph branches (engine/schedule.py).  One stream is the default
+        # since round 3: the kernels of two branches time-slice the SIMDs instead of filling each other's bubbles
+        # (profiles/r03_concurrency_study.md); with the hourglass' up-sampled residuals folded into the producing
+        # convolutions (planner R3) one stream is 2 % faster than two on the MPII model, 12 % on the PennAction merge
+        # model and 7 % on SPNet-NTU (frame-sharded stages)
+        self.num_streams = max(1, int(__import__('os').environ.get('DEEPHAR_STREAMS', '1')))
         # uint8 inputs are raw frames: predict() normalises them on the GPU exactly like the reference's loaders do
         # on the host (utils/transform.normalize_channels(frame, channel_power), transform.py:212-231)
         self.channel_power = 1

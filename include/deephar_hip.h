@@ -77,6 +77,10 @@ typedef struct dh_conv_args {
                       inputs / outputs / epilogue; per-product error <= 2^-23 relative, i.e. below the rounding of the
                       fp32 accumulation -- NOT bit-identical to w_split = 0.  Only shapes the LDS-DMA GEMM covers
                       (pointwise, or K x K with Cin % 32 == 0; 16-byte aligned x; no BN prologue), else DH_EUNSUPPORTED */
+  int32_t res2_down; /* 1: res2 is at HALF the output resolution, [N, OH/2, OW/2, Cout]: out(oh, ow) += res2(oh/2, ow/2), i.e.
+                        add([., UpSampling2D((2, 2))(res2)]) with the up-sampling folded into the residual read
+                        (reception.py:122-127: `b = UpSampling2D((2, 2))(b); x = add([a, b])` fused into the convolution
+                        that produces a).  Needs OH, OW even and up2 = 0 */
 } dh_conv_args;
 
 /* padded dims of the packed weight for a [KH,KW,Cin,Cout] (Keras HWIO) kernel */

@@ -130,6 +130,28 @@ def test_full_size_properties_batch64(hip_lib, cuda):
         assert a[k][..., :2].min() >= 0.0 and a[k][..., :2].max() <= 1.0
 
 
+def test_multi_stream_plans_are_bit_identical(hip_lib, cuda):
+    """Model.num_streams > 1 (independent branches on parallel hipGraph branches; opt-in since round 3) changes the
+    schedule and the arena layout, never a result bit -- eager and captured."""
+    x = np.random.default_rng(10).uniform(-1, 1, (3, 256, 256, 3)).astype(np.float32)
+    m, _ = _build(2, 2, 16, num_context_per_joint=2)
+    assert m.num_streams == 1 and m.plan.nstreams == 1
+    ref = m.predict(x, batch_size=3)
+    for ns in (2, 3):
+        m.num_streams = ns                                # re-plans
+        assert m.plan.nstreams == ns and len({s.stream for s in m.plan.steps}) == ns
+        assert np.array_equal(m.predict(x, batch_size=3), ref)
+        assert np.array_equal(m.predict(x, batch_size=3), ref)          # second call: hipGraph replay
+        m.executor.use_graph = False
+        assert np.array_equal(m.predict(x[:2], batch_size=2), ref[:2])    # eager multi-stream launch
+    sp, _, _, _ = _spnet(4, 'pa17j3d', 60, 2, [1, 2], 192)
+    clips = np.random.default_rng(11).uniform(-1, 1, (1, 4, 256, 256, 3)).astype(np.float32)
+    one = sp.predict(clips, batch_size=1)
+    sp.num_streams = 2
+    for a, b in zip(one, sp.predict(clips, batch_size=1)):
+        assert np.array_equal(a, b)
+
+
 def test_predict_accepts_float64_and_partial_batches(hip_lib, cuda):
     m, _ = _build(2, 1, 16, num_context_per_joint=2)
     x = np.random.default_rng(6).uniform(-1, 1, (5, 256, 256, 3))     # float64, like loader.py:139-140

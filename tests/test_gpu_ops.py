@@ -355,6 +355,46 @@ def test_kxk_conv_on_the_dma_kernel(case, cfg, hip_lib, cuda):
     _close(a, ref, atol=5e-5, what='kxk dma conv')
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize('case', [(2, 32, 32, 576, 576, False), (3, 16, 16, 288, 288, False), (2, 32, 32, 64, 100, True),
+                                  (1, 8, 8, 48, 40, False)])
+def test_conv2d_second_residual_at_half_resolution(case, hip_lib, cuda):
+    """dh_conv_args.res2_down: out = BN(conv(x)) + res1 + UpSampling2D(res2) with res2 at half resolution -- the
+    hourglass' add([a, UpSampling2D(b)]) (reception.py:122-127) folded into the convolution that produces a.  Equal, bit
+    for bit, to adding the explicitly up-sampled tensor as a full-resolution residual, on every tiling and in bf16x3."""
+    from deephar_amd import functional as F
+    n, h, w, cin, cout, relu = case
+    rng = np.random.default_rng(sum(int(v) for v in case))
+    x, k = _rand(rng, (n, h, w, cin)), _rand(rng, (1, 1, cin, cout), np.sqrt(1.0 / cin))
+    sc, sh = rng.uniform(0.5, 1.5, cout).astype(np.float32), _rand(rng, (cout,), 0.1)
+    r1, r2 = _rand(rng, (n, h, w, cout)), _rand(rng, (n, h // 2, w // 2, cout))
+    up = np.repeat(np.repeat(r2, 2, axis=1), 2, axis=2)
+    d = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(cuda)
+    kw = dict(pre_relu=relu, post_scale=d(sc), post_shift=d(sh), res1=d(r1))
+    for split in (False, True):
+        if split and cout % 4:
+            continue
+        ncfg = hip_lib.dh_conv2d_num_split_tile_cfgs() if split else hip_lib.dh_conv2d_num_tile_cfgs()
+        done = 0
+        for cfg in range(-1, ncfg):
+            try:
+                got = F.conv2d(d(x), k, res2=d(r2), res2_down=True, tile_cfg=cfg, split=split, **kw)
+                want = F.conv2d(d(x), k, res2=d(up), tile_cfg=cfg, split=split, **kw)
+            except Exception as e:
+                assert 'rc=-2' in str(e), e
+                continue
+            assert torch.equal(got, want), (split, cfg)
+            done += 1
+        assert done >= 4
+    xin = torch.from_numpy(x).double()
+    ref = O.conv2d(O.relu(xin) if relu else xin, torch.from_numpy(k).double(), (1, 1), 'same')
+    ref = ref * torch.from_numpy(sc).double() + torch.from_numpy(sh).double() + torch.from_numpy(r1).double() + \
+        torch.from_numpy(up).double()
+    _close(F.conv2d(d(x), k, res2=d(r2), res2_down=True, **kw), ref, atol=5e-5, what='res2_down')
+    with pytest.raises(Exception):
+        F.conv2d(d(x), k, res2=d(r2), res2_down=True, up2=True, **kw)
+
+
 # ---- halo-resident K x K kernel (dh_conv_args.w_split = 2, conv_halo.hip) ------------------------------------------------
 HALO_CASES = [
     # n, h, w, cin, cout, kh, kw, relu prologue, residual

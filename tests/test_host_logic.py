@@ -120,7 +120,15 @@ def test_planner_fusion_rules():
     # nothing but kernels that exist; BN / ReLU / add / concat / upsample never survive as their own launch
     assert set(kinds) <= {'conv', 'dwconv', 'pool', 'sam', 'context_agg'}
     convs = [s for s in plan.steps if s.kind == 'conv']
-    assert sum(1 for s in convs if s.attrs['up2']) == 4            # two fused up-samplings per hourglass
+    # R3: both add([a, UpSampling2D(b)]) of every hourglass are second residuals, read at half resolution, of the
+    # convolutions that produce `a`; those are emitted after the low-resolution branch that produces `b`
+    down = [s for s in convs if s.attrs['res2_down']]
+    assert len(down) == 4 and not any(s.attrs['up2'] for s in convs)
+    for s in down:
+        y, r2 = s.outs['y'], s.ins['res2']
+        assert (r2.shape[-3], r2.shape[-2], r2.C) == (y.shape[-3] // 2, y.shape[-2] // 2, y.C) and 'res1' in s.ins
+        writer = max(i for i, q in enumerate(plan.steps) if any(v is not None and v.buf is r2.buf for v in q.outs.values()))
+        assert writer < plan.steps.index(s)
     assert any('res1' in s.ins and 'res2' in s.ins and not s.attrs['up2'] for s in convs)   # 3-way add
     first = plan.steps[0]
     assert first.attrs['post_relu'] == 1 and 'post_bn' in first.params and first.attrs['pt'] == 0  # TF-SAME s2
@@ -327,8 +335,8 @@ def test_engine_options_replan_the_model():
     assert m._plan is None and m._exec is None
     p2 = m.plan
     assert p2 is not p1 and p2.gemm_precision == 'bf16x3'
-    m.num_streams = 1
-    assert m._plan is None and m.plan.nstreams == 1
+    m.num_streams = 2
+    assert m._plan is None and m.plan.nstreams == 2
 
 
 def test_split_eligibility_is_the_librarys_answer(hip_lib):

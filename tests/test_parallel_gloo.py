@@ -117,10 +117,10 @@ def test_stage_models_inherit_engine_options():
     stream count): bench.py --gemm bf16x3 --workload penn_merge must not silently run fp32 stages."""
     from deephar_amd import parallel
     m, _ = _build()
-    m.gemm_precision, m.num_streams = 'bf16x3', 1
+    m.gemm_precision, m.num_streams = 'bf16x3', 2
     sh = parallel.ShardedClipModel(m, rank=0, world=2, frame_fn=lambda x: x, head_fn=lambda t: t)
     for stage in (sh.frame_model, sh.head_model):
-        assert (stage.gemm_precision, stage.num_streams) == ('bf16x3', 1)
+        assert (stage.gemm_precision, stage.num_streams) == ('bf16x3', 2)
         assert stage.plan.gemm_precision == 'bf16x3'
 
 
