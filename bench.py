@@ -246,7 +246,7 @@ def roofline(rows, kinds, total_flops_per_step, ms_per_step):
              #  runs at 4.3-4.5 TB/s, torch's copy_ of the same tensor at 5.1: tools/micro/hbm_copy.py)
              'latency_bound_kernels': {k: {'launches': v['launches'], 'avg_us': round(1e3 * v['ms'] / v['launches'], 1),
                                            'MB_per_launch': round(v['bytes'] / v['launches'] / 1e6, 2)}
-                                       for k, v in sorted(kinds.items()) if k in ('sam', 'context_agg') and v['ms'] > 0}}
+                                       for k, v in sorted(kinds.items()) if k in ('sam', 'sam_ctx', 'context_agg') and v['ms'] > 0}}
     return out, extra
 
 

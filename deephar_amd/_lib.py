@@ -66,6 +66,7 @@ SIGNATURES = {
     'dh_upsample2x_add_f32': (C.c_int, [vp, C.c_int, vp, C.c_int, vp, C.c_int] + [C.c_int] * 4 + [vp]),
     'dh_eltwise_f32': (C.c_int, [C.POINTER(EltArgs), vp]),
     'dh_softargmax2d_f32': (C.c_int, [C.POINTER(SamArgs), vp]),
+    'dh_softargmax2d_context_f32': (C.c_int, [C.POINTER(SamArgs), C.c_int, C.c_int, C.c_float, vp, C.c_int, vp]),
     'dh_context_aggregation_f32': (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, vp]),
     'dh_depth_means_f32': (C.c_int, [vp, C.c_int, vp, vp] + [C.c_int] * 4 + [vp]),
     'dh_softargmax1d_f32': (C.c_int, [vp, vp, vp, C.c_int, vp] + [C.c_int] * 3 + [vp]),

@@ -143,6 +143,12 @@ int dh_softargmax2d_f32(const dh_sam_args* a, void* stream) {
   return launch_softargmax2d(*a, S(stream));
 }
 
+int dh_softargmax2d_context_f32(const dh_sam_args* a, int J, int nctx, float agg_alpha, float* y, int ldy,
+                                void* stream) {
+  if (a == nullptr) return DH_EINVAL;
+  return launch_softargmax2d_context(*a, J, nctx, agg_alpha, y, ldy, S(stream));
+}
+
 int dh_context_aggregation_f32(const float* ys, const float* yc, const float* pc, float* y, int F, int J,
                                int nctx, float alpha, int ldy, void* stream) {
   if (ys == nullptr || yc == nullptr || pc == nullptr || y == nullptr || ldy < 2) return DH_EINVAL;

@@ -180,6 +180,128 @@ __global__ __launch_bounds__(NTH) void softargmax2d_kernel(const SamArgs p) {
   }
 }
 
+// Soft-argmax + context aggregation in ONE launch (blocks.build_context_aggregation, blocks.py:217-285, on top of the two
+// read-outs of reception.pose_regression_2d_context, reception.py:167-182): the joints' own maps are channels [0, J) of
+// the heat-map tensor, joint j's nctx context maps are channels J + j*nctx + k.  Work-group = (frame, group of four
+// joints): 4 + 4 nctx <= 16 channel lanes x NT / 16 pixel lanes, the same two passes as softargmax2d_kernel<16, true>; the
+// twelve (x, y, confidence) triples meet in LDS and four threads write
+//     y_j = alpha ys_j + (1 - alpha) sum_k yc_jk pc_jk / sum_k pc_jk        (same operation order as context_agg_kernel)
+// and the joints' confidences.  Replaces three launches (two soft-argmax, one aggregation) of a few microseconds of
+// work each: on one stream their launch gaps and ramps are paid in full.
+template <int NT>
+__global__ __launch_bounds__(NT) void softargmax2d_ctx_kernel(const SamArgs p, const int J, const int nctx,
+                                                               const float agg_alpha, float* __restrict__ y,
+                                                               const int ldy) {
+  constexpr int NWV = NT / 64;      // waves
+  constexpr int PLN = NT / CG;      // pixel lanes
+  __shared__ float red[5][NWV][CG];
+  __shared__ float fin[3][CG];
+  extern __shared__ __attribute__((aligned(16))) float slab[];   // [H*W][CG], then gx[W], gy[H]
+  const int tid = threadIdx.x;
+  const int cc = tid % CG, pl = tid / CG;
+  const int wave = tid >> 6;
+  const int groups = (J + 3) / 4;
+  const int f = blockIdx.x / groups;
+  const int j0 = (blockIdx.x % groups) * 4;
+  const int nch = 4 + 4 * nctx;
+  const int HW = p.H * p.W;
+  // channel of lane cc: joints j0 .. j0+3, then their contexts
+  const int jj = cc < 4 ? cc : (cc - 4) / nctx;
+  const int c = cc < 4 ? j0 + cc : J + (j0 + jj) * nctx + (cc - 4) % nctx;
+  const bool cok = cc < nch && j0 + jj < J;
+
+  float* sgx = slab + HW * CG;
+  float* sgy = sgx + p.W;
+  {
+    const float* src = p.h + (size_t)f * HW * p.ldh;
+    const int per = 1 + nctx;                           // float4 per pixel: the joints' quad, then nctx context quads
+    const int total = HW * per;
+    for (int i0 = tid; i0 < total; i0 += 8 * NT) {
+      float4 t[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        int i = i0 + k * NT;
+        i = i < total ? i : total - 1;
+        const int px = i / per, q = i - px * per;
+        const int ch = q == 0 ? j0 : J + j0 * nctx + (q - 1) * 4;
+        t[k] = *reinterpret_cast<const float4*>(src + (size_t)px * p.ldh + ch);
+      }
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const int i = i0 + k * NT;
+        if (i < total) {
+          const int px = i / per, q = i - px * per;
+          *reinterpret_cast<float4*>(&slab[px * CG + q * 4]) = t[k];
+        }
+      }
+    }
+    for (int i = tid; i < p.W; i += NT) sgx[i] = p.gx[i];
+    for (int i = tid; i < p.H; i += NT) sgy[i] = p.gy[i];
+    __syncthreads();
+  }
+  auto at = [&](int px) -> float { return slab[px * CG + cc]; };
+
+  float vmax = -INFINITY, cmax = -INFINITY;
+  if (cok) {
+    for (int px = pl; px < HW; px += PLN) {
+      const float v = at(px);
+      vmax = fmaxf(vmax, p.alpha * v);
+      const int r = px / p.W, q = px - r * p.W;
+      if (r + 1 < p.H && q + 1 < p.W) {
+        const float s4 = ((v + at(px + 1)) + at(px + p.W)) + at(px + p.W + 1);
+        cmax = fmaxf(cmax, p.conf_scale * s4);
+      }
+    }
+  }
+  vmax = wave_max_cg(vmax);
+  cmax = wave_max_cg(cmax);
+  if ((tid & 63) < CG) { red[0][wave][cc] = vmax; red[1][wave][cc] = cmax; }
+  __syncthreads();
+  vmax = red[0][0][cc]; cmax = red[1][0][cc];
+#pragma unroll
+  for (int w = 1; w < NWV; ++w) { vmax = fmaxf(vmax, red[0][w][cc]); cmax = fmaxf(cmax, red[1][w][cc]); }
+
+  float s = 0.f, sx = 0.f, sy = 0.f;
+  if (cok) {
+    for (int px = pl; px < HW; px += PLN) {
+      const int r = px / p.W, q = px - r * p.W;
+      const float e = expf(p.alpha * at(px) - vmax);
+      s += e;
+      sx = fmaf(e, sgx[q], sx);
+      sy = fmaf(e, sgy[r], sy);
+    }
+  }
+  s = wave_sum_cg(s); sx = wave_sum_cg(sx); sy = wave_sum_cg(sy);
+  if ((tid & 63) < CG) { red[2][wave][cc] = s; red[3][wave][cc] = sx; red[4][wave][cc] = sy; }
+  __syncthreads();
+  if (tid < CG) {
+    s = red[2][0][cc]; sx = red[3][0][cc]; sy = red[4][0][cc];
+#pragma unroll
+    for (int w = 1; w < NWV; ++w) { s += red[2][w][cc]; sx += red[3][w][cc]; sy += red[4][w][cc]; }
+    s = fmaxf(s, 1e-7f);  // K.clip(sum, K.epsilon(), None), activations.py:12
+    const float inv = 1.f / s;
+    fin[0][cc] = sx * inv;
+    fin[1][cc] = sy * inv;
+    fin[2][cc] = cmax;
+  }
+  __syncthreads();
+  if (tid < 4 && j0 + tid < J) {
+    const int j = j0 + tid;
+    float sp = 0.f, spx = 0.f, spy = 0.f;
+    for (int k = 0; k < nctx; ++k) {
+      const int ci = 4 + tid * nctx + k;
+      const float pk = fin[2][ci];
+      sp += pk;
+      spx += fin[0][ci] * pk;
+      spy += fin[1][ci] * pk;
+    }
+    float* o = y + ((size_t)f * J + j) * ldy;
+    o[0] = agg_alpha * fin[0][tid] + (1.f - agg_alpha) * (spx / sp);
+    o[1] = agg_alpha * fin[1][tid] + (1.f - agg_alpha) * (spy / sp);
+    if (p.conf_raw != nullptr) p.conf_raw[((size_t)f * J + j) * p.ldcr] = fin[2][tid];
+  }
+}
+
 __global__ __launch_bounds__(256) void context_agg_kernel(const float* __restrict__ ys,
                                                           const float* __restrict__ yc,
                                                           const float* __restrict__ pc, float* __restrict__ y,
@@ -493,6 +615,24 @@ int launch_softargmax2d(const SamArgs& a, hipStream_t s) {
   } else {
     hipLaunchKernelGGL((softargmax2d_kernel<4, true>), grid, dim3(NTH), slab, s, a);
   }
+  return check_launch();
+}
+
+int launch_softargmax2d_context(const SamArgs& a, int J, int nctx, float agg_alpha, float* y, int ldy, hipStream_t s) {
+  if (a.F <= 0 || a.H <= 0 || a.W <= 0 || J <= 0 || nctx < 1 || nctx > 3 || y == nullptr || ldy < 2) return DH_EINVAL;
+  if (a.h == nullptr || a.gx == nullptr || a.gy == nullptr || a.C != J * (1 + nctx)) return DH_EINVAL;
+  if (a.xy != nullptr || a.conf_prob != nullptr || a.prob != nullptr || a.gmax != nullptr) return DH_EUNSUPPORTED;
+  // float4 staging: the joints' and the contexts' channel quads are 16-byte aligned runs of the pixel
+  if (J % 4 || a.ldh % 4 || (reinterpret_cast<uintptr_t>(a.h) & 15)) return DH_EUNSUPPORTED;
+  const size_t slab = ((size_t)a.H * a.W * CG + a.W + a.H) * sizeof(float);
+  if (slab > 128 * 1024) return DH_EUNSUPPORTED;
+  // 16 channel lanes x 64 pixel lanes: sixteen pixels per thread and pass, like the four-channel soft-argmax variant
+  constexpr int NT = 1024;
+  static bool once = (hipFuncSetAttribute((const void*)softargmax2d_ctx_kernel<NT>,
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024), true);
+  (void)once;
+  hipLaunchKernelGGL(softargmax2d_ctx_kernel<NT>, dim3((unsigned)(a.F * ((J + 3) / 4))), dim3(NT), slab, s, a, J, nctx,
+                     agg_alpha, y, ldy);
   return check_launch();
 }
 

@@ -28,6 +28,7 @@ int launch_upsample2x_add(const float* a, int lda, const float* b, int ldb, floa
                           int W, int C, hipStream_t s);
 int launch_eltwise(const EltArgs& a, hipStream_t s);
 int launch_softargmax2d(const SamArgs& a, hipStream_t s);
+int launch_softargmax2d_context(const SamArgs& a, int J, int nctx, float agg_alpha, float* y, int ldy, hipStream_t s);
 int launch_context_agg(const float* ys, const float* yc, const float* pc, float* y, int F, int J, int nctx,
                        float alpha, int ldy, hipStream_t s);
 int launch_depth_means(const float* h, int ldh, float* hxy, float* hz, int F, int HW, int D, int J,

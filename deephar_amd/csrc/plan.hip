@@ -12,7 +12,7 @@ namespace {
 
 using dh::check_launch;
 
-enum Fn { F_CONV, F_DW, F_POOL, F_UPADD, F_ELT, F_SAM, F_CTX, F_DMEANS, F_SAM1D, F_KRON, F_GMM, F_COPY, F_ZPAD, F_DFM, F_COUNT };
+enum Fn { F_CONV, F_DW, F_POOL, F_UPADD, F_ELT, F_SAM, F_CTX, F_DMEANS, F_SAM1D, F_KRON, F_GMM, F_COPY, F_ZPAD, F_DFM, F_SAMCTX, F_COUNT };
 
 struct Step { int fn; std::vector<unsigned char> payload; };
 struct In { size_t off, items; };
@@ -66,8 +66,16 @@ int struct_pointers(int fn) {
     case F_POOL: return 2;
     case F_ELT: return 6;
     case F_SAM: return 8;
+    case F_SAMCTX: return 8;
   }
   return -1;
+}
+// u64 arguments that follow the struct, and which of them are pointers
+void struct_extra(int fn, int* nargs, unsigned* ptr_mask) {
+  *nargs = 0;
+  *ptr_mask = 0;
+  if (fn == F_CONV) *nargs = 1;                                  // tile_cfg
+  if (fn == F_SAMCTX) { *nargs = 5; *ptr_mask = 0x08; }           // J, nctx, agg_alpha, y, ldy
 }
 size_t struct_size(int fn) {
   switch (fn) {
@@ -76,6 +84,7 @@ size_t struct_size(int fn) {
     case F_POOL: return sizeof(dh_pool_args);
     case F_ELT: return sizeof(dh_elt_args);
     case F_SAM: return sizeof(dh_sam_args);
+    case F_SAMCTX: return sizeof(dh_sam_args);
   }
   return 0;
 }
@@ -103,9 +112,19 @@ int run_step(const Step& st, void* stream) {
   auto Fl = [&](int i) { float f; std::memcpy(&f, p + 8 * i, 4); return f; };
   switch (st.fn) {
     case F_CONV: {
-      int cfg;
-      std::memcpy(&cfg, p + sizeof(dh_conv_args), 4);
-      return dh_conv2d_f32(reinterpret_cast<const dh_conv_args*>(p), cfg, stream);
+      int64_t cfg;
+      std::memcpy(&cfg, p + sizeof(dh_conv_args), 8);
+      return dh_conv2d_f32(reinterpret_cast<const dh_conv_args*>(p), (int)cfg, stream);
+    }
+    case F_SAMCTX: {
+      const unsigned char* e = p + sizeof(dh_sam_args);
+      int64_t J, nctx, ldy;
+      float alpha;
+      void* y;
+      std::memcpy(&J, e, 8); std::memcpy(&nctx, e + 8, 8); std::memcpy(&alpha, e + 16, 4);
+      std::memcpy(&y, e + 24, 8); std::memcpy(&ldy, e + 32, 8);
+      return dh_softargmax2d_context_f32(reinterpret_cast<const dh_sam_args*>(p), (int)J, (int)nctx, alpha,
+                                         static_cast<float*>(y), (int)ldy, stream);
     }
     case F_DW: return dh_dwconv2d_f32(reinterpret_cast<const dh_dw_args*>(p), stream);
     case F_POOL: return dh_pool2d_f32(reinterpret_cast<const dh_pool_args*>(p), stream);
@@ -169,13 +188,18 @@ int dh_plan_create(const void* blob, size_t blob_bytes, dh_plan** out) {
   for (Step& st : pl->steps) {
     const int np = struct_pointers(st.fn);
     if (np >= 0) {
-      if (st.payload.size() < struct_size(st.fn) + (st.fn == F_CONV ? 4 : 0)) return fail(DH_EINVAL);
-      for (int i = 0; i < np; ++i) {
+      int nextra;
+      unsigned emask;
+      struct_extra(st.fn, &nextra, &emask);
+      if (st.payload.size() != struct_size(st.fn) + (size_t)nextra * 8) return fail(DH_EINVAL);
+      for (int i = 0; i < np + nextra; ++i) {
+        if (i >= np && !(emask & (1u << (i - np)))) continue;
+        unsigned char* at = st.payload.data() + (i < np ? (size_t)8 * i : struct_size(st.fn) + (size_t)8 * (i - np));
         uint64_t v;
         void* ptr;
-        std::memcpy(&v, st.payload.data() + 8 * i, 8);
+        std::memcpy(&v, at, 8);
         if (!fix(*pl, v, &ptr)) return fail(DH_EINVAL);
-        std::memcpy(st.payload.data() + 8 * i, &ptr, 8);
+        std::memcpy(at, &ptr, 8);
       }
     } else {
       int nargs;

@@ -325,6 +325,21 @@ class BoundPlan:
             args.alpha, args.conf_scale = a['alpha'], a['conf_scale']
             self._keep.append(args)
             self.calls.append((lib.dh_softargmax2d_f32, (C.byref(args),), s))
+        elif k == 'sam_ctx':
+            h, y = s.ins['h'], s.outs['y']
+            H, W = h.shape[-3], h.shape[-2]
+            args = _lib.SamArgs()
+            args.h = P(h)
+            args.gx = self.store.constant(('gx', W), lambda: grid_x(W)).data_ptr()
+            args.gy = self.store.constant(('gx', H), lambda: grid_x(H)).data_ptr()
+            cr = s.outs.get('conf_raw')
+            if cr is not None:
+                args.conf_raw, args.ldcr = P(cr), cr.ld
+            args.F, args.H, args.W, args.C, args.ldh = n * h.lead(3), H, W, h.C, h.ld
+            args.alpha, args.conf_scale = a['sam_alpha'], a['conf_scale']
+            self._keep.append(args)
+            self.calls.append((lib.dh_softargmax2d_context_f32,
+                               (C.byref(args), a['J'], a['nctx'], a['alpha'], P(y), y.ld), s))
         elif k == 'context_agg':
             ys, y = s.ins['ys'], s.outs['y']
             self.calls.append((lib.dh_context_aggregation_f32,

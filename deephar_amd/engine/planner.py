@@ -610,7 +610,53 @@ class Planner:
     def op_expect2d(self, node):
         raise NotImplementedError('softargmax2d must be applied to the output of act_channel_softmax')
 
+    def _fused_decoder(self, node):
+        """R5b: the two soft-argmax read-outs (joint maps, context maps) feeding a context aggregation and the
+        aggregation itself as ONE launch (dh_softargmax2d_context_f32) when nothing else reads the intermediate
+        coordinates / confidences and the maps are the two channel runs [c0, c0+J), [c0+J, c0+J+J*nctx) of one tensor."""
+        nctx = node.attrs['nctx']
+        if any(self.n_consumers(t) != 1 for t in node.inputs) or not 1 <= nctx <= 3:
+            return None
+        vals = [self.val.get(t.uid) for t in node.inputs]
+        if any(v is None or isinstance(v, _Lazy) for v in vals):
+            return None
+        ys, yc, pc = vals
+        s_s, s_c = self.producer.get(id(ys)), self.producer.get(id(yc))
+        if s_s is None or s_c is None or s_s is s_c or s_s.kind != 'sam' or s_c.kind != 'sam' or \
+                self.producer.get(id(pc)) is not s_c or s_s.outs.get('xy') is not ys or s_c.outs.get('xy') is not yc or \
+                s_c.outs.get('conf_raw') is not pc:
+            return None
+        if set(k for k, v in s_s.outs.items() if v is not None) - {'xy', 'conf_raw'} or \
+                set(k for k, v in s_c.outs.items() if v is not None) != {'xy', 'conf_raw'}:
+            return None
+        if s_s.attrs != s_c.attrs or s_s.attrs.get('alpha') != 1.0:
+            return None
+        hs, hc = s_s.ins['h'], s_c.ins['h']
+        J = hs.C
+        if hs.buf is not hc.buf or hs.ld != hc.ld or hc.coff != hs.coff + J or hc.C != J * nctx or J % 4 or hs.ld % 4 or \
+                hs.coff % 4 or hs.shape[:-1] != hc.shape[:-1]:
+            return None
+        return s_s, s_c, Value(hs.shape[:-1] + (J * (1 + nctx),), hs.buf, hs.coff, hs.ld)
+
     def op_context_agg(self, node):
+        hit = self._fused_decoder(node)
+        if hit is not None:
+            s_s, s_c, h = hit
+            for st in (s_s, s_c):
+                self.plan.steps.remove(st)
+            for v in (s_s.outs['xy'], s_c.outs['xy'], s_c.outs['conf_raw']):
+                if v.buf in self.plan.bufs and not any(w is not None and w.buf is v.buf for q in self.plan.steps
+                                                        for w in list(q.ins.values()) + list(q.outs.values())):
+                    self.plan.bufs.remove(v.buf)
+            y = self.out_value_for(node.outputs[0])
+            outs = dict(y=y)
+            if s_s.outs.get('conf_raw') is not None:
+                outs['conf_raw'] = s_s.outs['conf_raw']
+            attrs = dict(node.attrs)
+            attrs.update(J=s_s.ins['h'].C, sam_alpha=s_s.attrs['alpha'], conf_scale=s_s.attrs['conf_scale'])
+            self.emit('sam_ctx', dict(h=h), outs, attrs, name=node.name)
+            self.val[node.outputs[0].uid] = y
+            return
         ys, yc, pc = [self.materialize(t) for t in node.inputs]
         for v in (ys, yc, pc):
             assert v.dense, 'context aggregation expects dense operands'

@@ -6,8 +6,8 @@ Blob (little endian):
     inputs   per input : u64 arena byte offset | u64 floats per batch item
     outputs  per output: u64 arena byte offset | u64 pixels per batch item | u32 channels | u32 pixel pitch (floats)
     steps    per launch: u32 function id | u32 payload bytes | payload
-               struct functions: the argument struct, byte for byte (+ i32 tile_cfg for dh_conv2d_f32)
-               scalar functions: one u64 per argument (ints sign-extended, floats as their bit pattern)
+               struct functions: the argument struct, byte for byte, then one u64 per further argument
+               scalar functions: one u64 per argument (ints sign-extended, floats as their bit pattern in the low half)
              every device pointer (struct field or scalar) is written as 0 (NULL) or (region << 60) | byte offset,
              region 1 = the activation arena, 2 = the weight image
     weights  the weight image (packed conv / depthwise kernels, BN affines, grids), every tensor 256-byte aligned
@@ -25,7 +25,7 @@ MAGIC, VERSION = b'DHPL', 1
 FUNCTIONS = ['dh_conv2d_f32', 'dh_dwconv2d_f32', 'dh_pool2d_f32', 'dh_upsample2x_add_f32', 'dh_eltwise_f32',
              'dh_softargmax2d_f32', 'dh_context_aggregation_f32', 'dh_depth_means_f32', 'dh_softargmax1d_f32',
              'dh_kronecker_f32', 'dh_global_maxmin_softmax_f32', 'dh_copy_channels_f32', 'dh_zeropad2d_f32',
-             'dh_depth_from_maps_f32']
+             'dh_depth_from_maps_f32', 'dh_softargmax2d_context_f32']
 ARENA, WEIGHTS = 1, 2
 
 
@@ -64,6 +64,19 @@ def _is_ptr_type(t):
     return t is C.c_void_p
 
 
+def _scalars(sig, args, reg):
+    assert len(sig) == len(args), (len(sig), len(args))
+    parts = []
+    for t, a in zip(sig, args):
+        if _is_ptr_type(t):
+            parts.append(struct.pack('<Q', reg.tag(a)))
+        elif t is C.c_float:
+            parts.append(struct.pack('<fI', float(a), 0))
+        else:
+            parts.append(struct.pack('<q', int(a)))
+    return b''.join(parts)
+
+
 def dump_plan(model, batch):
     """-> bytes.  `model`'s plan bound (and autotuned) for `batch`; needs a HIP device (the weight image is read back)."""
     ex = model.executor
@@ -92,18 +105,9 @@ def dump_plan(model, batch):
                 if _is_ptr_type(ftype):
                     off = getattr(type(obj), fname).offset
                     raw[off:off + 8] = struct.pack('<Q', reg.tag(getattr(obj, fname)))
-            payload = bytes(raw) + b''.join(struct.pack('<i', int(a)) for a in args[1:])
+            payload = bytes(raw) + _scalars(sig[1:], args[1:], reg)
         else:
-            assert len(sig) == len(args), (name, len(sig), len(args))
-            parts = []
-            for t, a in zip(sig, args):
-                if _is_ptr_type(t):
-                    parts.append(struct.pack('<Q', reg.tag(a)))
-                elif t is C.c_float:
-                    parts.append(struct.pack('<fI', float(a), 0))
-                else:
-                    parts.append(struct.pack('<q', int(a)))
-            payload = b''.join(parts)
+            payload = _scalars(sig, args, reg)
         steps.append(struct.pack('<II', names[name], len(payload)) + payload)
     plan = bp.plan
     head = MAGIC + struct.pack('<IiQQIII', VERSION, bp.n, bp.arena.numel() * 4, (reg.size + 255) & ~255,

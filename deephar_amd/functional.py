@@ -180,6 +180,27 @@ def softargmax2d(h, alpha=1.0, conf_scale=1.0, want_prob=False):
     return out
 
 
+def softargmax2d_context(h, joints, num_context, agg_alpha, alpha=1.0, conf_scale=1.0, pitch=None):
+    """dh_softargmax2d_context_f32: h [F, H, W, >= J*(1+nctx)] (channel pitch = h.shape[-1], the first J*(1+nctx)
+    channels are read) -> (pose [F, J, 2], joint confidences [F, J, 1])."""
+    torch = _t()
+    _chk(h)
+    f, hh, ww, ld = h.shape
+    dev = h.device
+    y = torch.empty((f, joints, 2), device=dev)
+    conf = torch.empty((f, joints, 1), device=dev)
+    gx = torch.from_numpy(grid_x(ww)).to(dev)
+    gy = torch.from_numpy(grid_x(hh)).to(dev)
+    a = _lib.SamArgs()
+    a.h, a.gx, a.gy, a.conf_raw = _p(h), _p(gx), _p(gy), _p(conf)
+    a.F, a.H, a.W, a.C, a.ldh, a.ldcr = f, hh, ww, joints * (1 + num_context), ld, 1
+    a.alpha, a.conf_scale = float(alpha), float(conf_scale)
+    _lib.check(_lib.load().dh_softargmax2d_context_f32(C.byref(a), joints, num_context, float(agg_alpha), _p(y), 2,
+                                                       _stream()), 'dh_softargmax2d_context_f32')
+    torch.cuda.current_stream().synchronize()  # gx/gy are temporaries
+    return y, conf
+
+
 def context_aggregation(ys, yc, pc, num_context, alpha):
     torch = _t()
     _chk(ys, yc, pc)

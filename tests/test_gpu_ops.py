@@ -235,6 +235,36 @@ def test_softargmax2d_known_answers(hip_lib, cuda):
     np.testing.assert_allclose(flat, 0.5, atol=1e-6)
 
 
+@pytest.mark.parametrize('shape,joints,nctx', [((3, 32, 32, 48), 16, 2), ((2, 16, 16, 52), 12, 3), ((2, 32, 32, 8), 4, 1),
+                                               ((1, 8, 8, 64), 16, 2)])
+def test_softargmax2d_with_context_in_one_launch(shape, joints, nctx, hip_lib, cuda):
+    """dh_softargmax2d_context_f32 = the 2-D decoder with context of reception.pose_regression_2d_context in one launch:
+    against the oracle's soft-argmax / keypoint confidence / context aggregation (1e-3 px on the pose) and against the
+    three-launch path it replaces (same maps: coordinates agree to fp32 rounding)."""
+    from deephar_amd import functional as F
+    f, hh, ww, ld = shape
+    rng = np.random.default_rng(sum(shape) + nctx)
+    h = _rand(rng, shape, 4.0) + 1.0                     # (positive offset: context confidences away from 0)
+    t = torch.from_numpy(h)
+    c = joints * (1 + nctx)
+    pose, conf = F.softargmax2d_context(t.to(cuda), joints, nctx, 0.8, conf_scale=1.0)
+    hs, hc = t[..., :joints].double(), t[..., joints:c].double()
+    ys = O.softargmax2d_from_prob(O.channel_softmax_2d(hs, 1.0))
+    yc = O.softargmax2d_from_prob(O.channel_softmax_2d(hc, 1.0))
+    pc = O.joints_probability(hc)
+    assert float(pc.reshape(f, joints, nctx).sum(-1).min()) > 1.0
+    ref = O.context_aggregation(ys, yc, pc, joints, nctx, 0.8)
+    assert (pose.cpu().double() - ref).abs().max().item() <= 3.9e-6
+    _close(conf, O.joints_probability(hs), atol=1e-5, what='joint confidence')
+    d = t.to(cuda)
+    a = F.softargmax2d(d[..., :joints].contiguous())
+    b = F.softargmax2d(d[..., joints:c].contiguous())
+    three = F.context_aggregation(a['xy'], b['xy'], b['conf_raw'], nctx, 0.8)
+    assert float((three - pose).abs().max()) <= 2e-6 and torch.equal(a['conf_raw'], conf)
+    with pytest.raises(Exception):
+        F.softargmax2d_context(torch.zeros(1, 8, 8, 15, device=cuda), 5, 2, 0.8)      # J % 4 != 0: not this kernel
+
+
 def test_context_aggregation(hip_lib, cuda):
     from deephar_amd import functional as F
     rng = np.random.default_rng(11)

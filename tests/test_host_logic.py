@@ -118,7 +118,7 @@ def test_planner_fusion_rules():
     plan = m.plan
     kinds = [s.kind for s in plan.steps]
     # nothing but kernels that exist; BN / ReLU / add / concat / upsample never survive as their own launch
-    assert set(kinds) <= {'conv', 'dwconv', 'pool', 'sam', 'context_agg'}
+    assert set(kinds) <= {'conv', 'dwconv', 'pool', 'sam_ctx'}
     convs = [s for s in plan.steps if s.kind == 'conv']
     # R3: both add([a, UpSampling2D(b)]) of every hourglass are second residuals, read at half resolution, of the
     # convolutions that produce `a`; those are emitted after the low-resolution branch that produces `b`
@@ -135,11 +135,16 @@ def test_planner_fusion_rules():
     # concat targets are written in place at channel offsets
     y = [s for s in plan.steps if s.kind == 'pool'][0].outs['y']
     assert (y.coff, y.ld) == (96, 160)
-    # decoder: heat-map slices are views; (x,y) and confidence land directly in the [J,3] output
-    sams = [s for s in plan.steps if s.kind == 'sam']
-    assert (sams[0].ins['h'].coff, sams[0].ins['h'].ld, sams[0].ins['h'].C) == (0, 48, 16)
-    assert (sams[1].ins['h'].coff, sams[1].ins['h'].C) == (16, 32)
-    assert sams[0].outs['conf_raw'].ld == 3 and sams[0].outs['conf_raw'].coff == 2
+    # decoder (R5 + R5b): both soft-argmax read-outs and the context aggregation are ONE launch per block over the 48
+    # heat-map channels; pose (x, y) and the joints' confidence land directly in the [J, 3] output
+    dec = [s for s in plan.steps if s.kind == 'sam_ctx']
+    assert len(dec) == 2
+    assert (dec[0].ins['h'].coff, dec[0].ins['h'].ld, dec[0].ins['h'].C) == (0, 48, 48)
+    assert (dec[0].attrs['J'], dec[0].attrs['nctx'], dec[0].attrs['alpha']) == (16, 2, 0.8)
+    assert dec[0].outs['y'].ld == 3 and dec[0].outs['conf_raw'].ld == 3 and dec[0].outs['conf_raw'].coff == 2
+    # ... unless something else reads the intermediate coordinates: exported heat-maps do not, exported poses would
+    kept = _mpii(1, num_context_per_joint=2, export_heatmaps=True).plan
+    assert sum(1 for s in kept.steps if s.kind == 'sam_ctx') == 1
 
 
 def test_memory_plan_has_no_live_overlap():
