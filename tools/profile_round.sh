@@ -1,15 +1,16 @@
 #!/bin/bash
 # Round profile on the GPU box (gpurun): rocprofv3 kernel stats of the contract bench (1 and 2 graph branches) and PMC
 # passes (separate runs, one counter group each) of the dominant GEMM instantiations on the dominant shape.
-#   /usr/local/graft/bin/gpurun --timeout 1500 -- 'bash tools/profile_round.sh r02'
+#   /usr/local/graft/bin/gpurun --timeout 1500 -- 'bash tools/profile_round.sh r03'
 # Summaries land in gpurun_out/<tag>_*; copy the ones to keep into profiles/.
-TAG=${1:-r02}
+TAG=${1:-r03}
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
 OUT=$GRAFT_REPO_ROOT/gpurun_out
+rm -f $OUT/${TAG}_pmc_summary.txt $OUT/${TAG}_pmc_summary_bf16x3.txt $OUT/${TAG}_tune*.json
 B="--no-cpu-baseline --no-predict --no-clip-leg --no-bf16x3 --tune-cache $OUT/${TAG}_tune.json"
 python bench.py $B --steps 10 > $OUT/${TAG}_b0.log 2>&1
-for S in 2 1; do
+for S in 1 2; do
   (cd /tmp && rocprofv3 --kernel-trace --stats -d $OUT/${TAG}_prof_s$S -o out -- python $GRAFT_REPO_ROOT/bench.py $B --steps 20 --warmup 3 --streams $S > $OUT/${TAG}_prof_s$S.log 2>&1)
   DB=$(ls $OUT/${TAG}_prof_s$S/*/*results.db $OUT/${TAG}_prof_s$S/*results.db 2>/dev/null | head -1)
   [ -n "$DB" ] && python tools/rocpd_stats.py kernels $DB $OUT/${TAG}_bench_kernel_stats_streams$S.csv
@@ -35,7 +36,8 @@ for C in FETCH_SIZE WRITE_SIZE SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE; do
 done
 cat $OUT/${TAG}_pmc_summary.txt $OUT/${TAG}_pmc_summary_bf16x3.txt
 tail -1 $OUT/${TAG}_prof_b3.log | cut -c1-300
-tail -1 $OUT/${TAG}_prof_s2.log | cut -c1-400
-head -12 $OUT/${TAG}_bench_kernel_stats_streams2.csv
+tail -1 $OUT/${TAG}_prof_s1.log | cut -c1-400
+head -12 $OUT/${TAG}_bench_kernel_stats_streams1.csv
+python tools/make_pmc_json.py $OUT/${TAG}_pmc_summary.txt $OUT/${TAG}_pmc_summary_bf16x3.txt > $OUT/${TAG}_pmc_dominant_kernel.json
 # keep the merged-back payload small
 rm -rf $OUT/${TAG}_prof_s1 $OUT/${TAG}_prof_s2 $OUT/${TAG}_prof_b3 $OUT/${TAG}_pmc_1* $OUT/${TAG}_pmc_w_*
