@@ -501,6 +501,8 @@ class BoundPlan:
                 step.attrs['split_k'] = True
                 self.calls[i] = (fn, (args[0], -1), step)
                 continue
+            shape_key = ('shape', int(cargs.w_split), self.n, cargs.N * cargs.OH * cargs.OW, cargs.K, cargs.Cout, cargs.KH,
+                         cargs.KW, cargs.up2)
             if sig not in table:
                 def time_cfg(cfg, nrep, trials):
                     t_cfg = float('inf')
@@ -529,9 +531,16 @@ class BoundPlan:
                         for c in close:
                             timed[c] = time_cfg(c, 4 * reps, 3)
                         best = min(close, key=lambda c: timed[c])
+                        # tilings within 1 % of each other are the same speed as far as this timing can tell: the same
+                        # GEMM (M x K x N, taps) under another epilogue signature keeps the tiling chosen first, so one
+                        # layer family runs ONE instantiation (per-kernel profiles stay readable, PMC look-ups hit)
+                        pref = table.get(shape_key)
+                        if pref in close and timed[pref] <= 1.01 * timed[best]:
+                            best = pref
                     else:
                         best = close[0]
                 table[sig] = best
+                table.setdefault(shape_key, best)
             step.attrs['tile_cfg'] = table[sig]
             self.calls[i] = (fn, (args[0], table[sig]), step)
         lib.dh_event_destroy(e0)

@@ -15,8 +15,8 @@ for S in 1 2; do
   DB=$(ls $OUT/${TAG}_prof_s$S/*/*results.db $OUT/${TAG}_prof_s$S/*results.db 2>/dev/null | head -1)
   [ -n "$DB" ] && python tools/rocpd_stats.py kernels $DB $OUT/${TAG}_bench_kernel_stats_streams$S.csv
 done
-# PMC: gemm1x1 <4,1,1,3> (cfg 11) and <4,1,1,2> (cfg 12), pre_relu = 0 -> the <.., false, false, false> instantiations
-for CFG in 11 12; do
+# PMC: gemm1x1 <2,2,2,3> (cfg 9), <4,1,1,3> (11), <4,1,1,2> (12), <4,1,1,1> (13), pre_relu = 0 -> the <.., false, false, false> instantiations
+for CFG in 9 11 12 13; do
  for C in FETCH_SIZE WRITE_SIZE SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE; do
   (cd /tmp && rocprofv3 --pmc $C --kernel-trace -d $OUT/${TAG}_pmc_${CFG}_$C -o out -- python $GRAFT_REPO_ROOT/tools/bench_one.py 32 576 576 1 1 $CFG 4 0 > /dev/null 2>&1)
   DB=$(ls $OUT/${TAG}_pmc_${CFG}_$C/*/*results.db $OUT/${TAG}_pmc_${CFG}_$C/*results.db 2>/dev/null | head -1)
