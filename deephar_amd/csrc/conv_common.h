@@ -32,6 +32,7 @@ __device__ __forceinline__ int xcd_tile(int b, int nwg) {
 // the BN affine / residual loads / stores are 16-byte wide and whole output rows are contiguous.
 //   out = relu?( acc*post_scale + post_shift + res1[m] + res2[mo] ), optionally written 2x up-sampled, or with
 //   res2 read at half resolution (res2_down: the UpSampling2D sits on the residual instead of on the result).
+//   Optionally also writes the 2x2 max-pooled output (y_pool).
 //
 // The epilogue is latency-, not bandwidth-bound: a work-group that loads its residual tile only after the last
 // MFMA sits through one HBM round trip per dependent batch while the other work-groups of the CU -- started
@@ -73,6 +74,11 @@ struct EpiPrefetch {
   }
 };
 
+// Tilings whose epilogue can also write the 2x2 max-pooled output (dh_conv_args.y_pool): every wave owns ONE 32-row
+// block = one image row at OW == 32, and the waves come in (even, odd) pairs over M.
+template <int WM, int TM, bool UP2>
+constexpr bool conv_epilogue_pools() { return TM == 1 && WM % 2 == 0 && !UP2; }
+
 struct EpiNoHook {
   __device__ __forceinline__ void operator()() const {}
 };
@@ -94,6 +100,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x16 (&acc)[T
   constexpr int IT = 4 * TN;
   constexpr int NSC = (64 % ROW4 == 0) ? 1 : 3;   // distinct column groups a lane meets over the row loop
   constexpr bool kPre = PRE && EpiPrefetch<TM, TN>::kEnabled;
+  constexpr bool kPool = conv_epilogue_pools<WM, TM, UP2>();
   float* sC = smem + wave * 32 * LDC;
   const int ohw = p.OH * p.OW;
   const bool vec = epi_vec != 0;
@@ -220,6 +227,9 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x16 (&acc)[T
               o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f);
             }
             if (ok) st4_stream(p.y + mo[u][d] * p.ldy + nc, o);
+            if constexpr (kPool) {                                 // keep the final values: the pair pools them below
+              if (p.y_pool != nullptr) *reinterpret_cast<float4*>(&sC[row * LDC + c4 * 4]) = o;
+            }
           }
         }
       }
@@ -266,6 +276,35 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x16 (&acc)[T
           }
         }
       }
+    }
+  }
+  if constexpr (kPool) {
+    // MaxPooling2D((2, 2)) of what was just stored: the slabs now hold the FINAL values of the work-group's image rows
+    // (OW == 32: one row per wave); waves (2i, 2i+1) over M pool their two rows, 128 threads per pair
+    if (p.y_pool != nullptr && vec) {
+      __syncthreads();
+      const float* sE = smem + ((wm & ~1) * WN + wn) * 32 * LDC;
+      const float* sO = sE + WN * 32 * LDC;
+      const int r_img = m0 / 32 + (wm & ~1);                    // image row of the even wave (OW == 32)
+      if ((r_img + 2) * 32 <= M) {
+        const int fr = r_img / p.OH, oh = r_img - fr * p.OH;
+        const size_t pp = ((size_t)fr * (p.OH / 2) + oh / 2) * 16;
+        for (int idx = (wm & 1) * 64 + lane; idx < 16 * ROW4; idx += 128) {
+          const int q = idx / ROW4, c4 = idx - q * ROW4;
+          const int n = n0 + wn * TN * 32 + c4 * 4;
+          if (n >= p.Cout) continue;
+          const float4 a = *reinterpret_cast<const float4*>(&sE[(2 * q) * LDC + c4 * 4]);
+          const float4 b = *reinterpret_cast<const float4*>(&sE[(2 * q + 1) * LDC + c4 * 4]);
+          const float4 c = *reinterpret_cast<const float4*>(&sO[(2 * q) * LDC + c4 * 4]);
+          const float4 d = *reinterpret_cast<const float4*>(&sO[(2 * q + 1) * LDC + c4 * 4]);
+          float4 t;
+          t.x = fmaxf(fmaxf(a.x, b.x), fmaxf(c.x, d.x)); t.y = fmaxf(fmaxf(a.y, b.y), fmaxf(c.y, d.y));
+          t.z = fmaxf(fmaxf(a.z, b.z), fmaxf(c.z, d.z)); t.w = fmaxf(fmaxf(a.w, b.w), fmaxf(c.w, d.w));
+          *reinterpret_cast<float4*>(p.y_pool + (pp + q) * p.ldyp + n) = t;
+        }
+      }
+      __syncthreads();      // a kernel that runs this epilogue again through the same slabs (the split wide tiling's second
+                            // column slice) must not stage over rows its partner wave is still pooling
     }
   }
 }

@@ -192,6 +192,14 @@ int dh_plan_create(const void* blob, size_t blob_bytes, dh_plan** out) {
       unsigned emask;
       struct_extra(st.fn, &nextra, &emask);
       if (st.payload.size() != struct_size(st.fn) + (size_t)nextra * 8) return fail(DH_EINVAL);
+      if (st.fn == F_CONV) {                     // (y_pool sits behind the integer fields of dh_conv_args)
+        unsigned char* at = st.payload.data() + offsetof(dh_conv_args, y_pool);
+        uint64_t v;
+        void* ptr;
+        std::memcpy(&v, at, 8);
+        if (!fix(*pl, v, &ptr)) return fail(DH_EINVAL);
+        std::memcpy(at, &ptr, 8);
+      }
       for (int i = 0; i < np + nextra; ++i) {
         if (i >= np && !(emask & (1u << (i - np)))) continue;
         unsigned char* at = st.payload.data() + (i < np ? (size_t)8 * i : struct_size(st.fn) + (size_t)8 * (i - np));

@@ -244,6 +244,9 @@ class BoundPlan:
                 args.res2, args.ldr2 = P(r2), r2.ld
             args.pre_relu, args.post_relu, args.up2 = a['pre_relu'], a['post_relu'], a['up2']
             args.res2_down = a.get('res2_down', 0)
+            yp = s.outs.get('ypool')
+            if yp is not None:                         # planner rule R7: the 2x2 max-pooled second output
+                args.y_pool, args.ldyp = P(yp), yp.ld
             if self.u8 is not None and id(x.buf) in self.u8 and self.u8[id(x.buf)][2]:
                 buf, lut, _ = self.u8[id(x.buf)]
                 args.x, args.in_lut, args.x_u8 = buf.data_ptr(), lut.data_ptr(), 1
@@ -475,7 +478,7 @@ class BoundPlan:
                  r1.ld % 4 if r1 is not None else 0, r2.ld % 4 if r2 is not None else 0)
         return (x.lead(3), x.shape[-3], x.shape[-2], x.C, x.ld, y.ld, a['Cout'], a['kh'], a['kw'], a['sh'],
                 a['sw'], a['pre_relu'], a['post_relu'], a['up2'], 'res1' in step.ins, 'res2' in step.ins,
-                'pre_bn' in step.params, 'post_bn' in step.params, a['pt'], a['pl'], y.shape[-3], y.shape[-2], a.get('res2_down', 0)) + align
+                'pre_bn' in step.params, 'post_bn' in step.params, a['pt'], a['pl'], y.shape[-3], y.shape[-2], a.get('res2_down', 0), 'ypool' in step.outs) + align
 
     def autotune(self, stream_ptr, table=None, reps=3):
         """Time every tile configuration of dh_conv2d_f32 for each distinct conv shape of this bound plan

@@ -16,6 +16,8 @@ Fusion rules (what the reference leaves to TensorFlow as separate kernels):
                 epilogue at 2x resolution; a free-standing UpSampling2D -> add becomes one upsample_add kernel.
   R4 concat   : producers write straight into the concatenation buffer at their channel offset
                 (reception.py:75,83,87); Lambda channel slices are pointer/ld views (reception.py:171-172).
+  R7 pool     : MaxPooling2D((2, 2)) of a 32-column convolution output is a second output of that convolution's epilogue
+                (dh_conv_args.y_pool; reception.py:105-116).
   R5 decoder  : channel soft-max + both lin_interpolation_2d + joint confidence (+ global max) on the same
                 maps are one soft-argmax kernel (blocks.py:306-343).
 All tensors are fp32; sizes are tracked per batch item so one plan serves any batch size.
@@ -493,8 +495,25 @@ class Planner:
     def op_pool(self, node):
         x = self.materialize(node.inputs[0])
         y = self.out_value_for(node.outputs[0])
-        # (writing the 2x2 max-pool from the producing convolution's epilogue was built in round 2 and measured neutral:
-        # in seven of eight blocks the producer is the K = 48 fReMap GEMM, itself bound by its epilogue; removed)
+        # R7: MaxPooling2D((2, 2)) of a convolution's output at 32 columns is written by that convolution's epilogue as a
+        # second output (dh_conv_args.y_pool) -- the stand-alone pool reads the whole tensor back from HBM
+        # (reception.py:105-116: every hourglass level is used at full AND at half resolution).  Bit-identical.  Neutral
+        # while the pool ran beside other work on a second stream (round 2); on ONE stream, where the forward is the sum
+        # of its kernels, it is worth 1-2 % on the MPII model.  DEEPHAR_FUSE_POOL=0 switches it off.
+        a = node.attrs
+        prod = self.producer.get(id(x))
+        if os.environ.get('DEEPHAR_FUSE_POOL', '1') != '0' and prod is not None and prod.kind == 'conv' and \
+                prod.outs.get('y') is x and 'ypool' not in prod.outs and not prod.attrs.get('up2') and \
+                a.get('mode', 0) == 0 and (a['kh'], a['kw'], a['sh'], a['sw'], a['pt'], a['pl']) == (2, 2, 2, 2, 0, 0) and \
+                x.shape[-2] == 32 and x.shape[-3] % 2 == 0 and x.C % 4 == 0 and x.ld % 4 == 0 and y.ld % 4 == 0 and \
+                x.coff % 4 == 0 and y.coff % 4 == 0 and \
+                not (prod.attrs['kh'] * prod.attrs['kw'] > 1 and prod.attrs['Cin'] % 32 == 16) and \
+                not split_k_rule(x.shape[-3] * x.shape[-2], prod.attrs['K'], prod.attrs['Cout'], prod.attrs['Cin']):
+            prod.outs['ypool'] = y
+            prod.attrs['pool2'] = 1
+            self.producer[id(y)] = prod
+            self.val[node.outputs[0].uid] = y
+            return
         self.emit('pool', dict(x=x), dict(y=y), dict(node.attrs), name=node.name or 'pool')
         self.val[node.outputs[0].uid] = y
 

@@ -45,7 +45,7 @@ def pack_conv_weight(w_hwio, device='cuda'):
 
 def conv2d(x, w_hwio, strides=(1, 1), padding='same', pre_scale=None, pre_shift=None, pre_relu=False,
            post_scale=None, post_shift=None, post_relu=False, res1=None, res2=None, up2=False, tile_cfg=-1,
-           packed=None, in_lut=None, split=False, halo=False, res2_down=False):
+           packed=None, in_lut=None, split=False, halo=False, res2_down=False, pool2=False):
     """Fused conv (see dh_conv2d_f32).  x [N,H,W,Cin]; w_hwio numpy [kh,kw,Cin,Cout].  A uint8 `x` needs
     `in_lut` (float32 [Cin,256] device tensor, engine.executor.normalization_lut): bytes are normalised on load."""
     torch = _t()
@@ -91,8 +91,12 @@ def conv2d(x, w_hwio, strides=(1, 1), padding='same', pre_scale=None, pre_shift=
     a.res2_down = int(res2_down)
     if x.dtype == torch.uint8:
         a.in_lut, a.x_u8 = _p(in_lut), 1
+    yp = None
+    if pool2:                                    # second output: MaxPooling2D((2, 2)) of y (dh_conv_args.y_pool)
+        yp = torch.empty((n, oh // 2, ow // 2, cout), dtype=torch.float32, device=x.device)
+        a.y_pool, a.ldyp = _p(yp), cout
     _lib.check(lib.dh_conv2d_f32(C.byref(a), tile_cfg, _stream()), 'dh_conv2d_f32')
-    return y
+    return (y, yp) if pool2 else y
 
 
 def normalize_u8(x, lut):

@@ -81,6 +81,13 @@ typedef struct dh_conv_args {
                         add([., UpSampling2D((2, 2))(res2)]) with the up-sampling folded into the residual read
                         (reception.py:122-127: `b = UpSampling2D((2, 2))(b); x = add([a, b])` fused into the convolution
                         that produces a).  Needs OH, OW even and up2 = 0 */
+  int32_t ldyp;
+  float* y_pool; /* optional second output: MaxPooling2D((2, 2)) of the convolution's FINAL output (after BN / residuals /
+                    ReLU), [N, OH/2, OW/2, Cout] with pixel pitch ldyp -- the hourglass reads every level both at full and
+                    at half resolution (reception.py:105-116: x = ...; MaxPooling2D((2, 2))(x)), and a stand-alone pool
+                    has to read the whole tensor back.  Built for OW == 32, OH even, 16-byte aligned rows, no up2, on the
+                    tilings whose waves own 32-row blocks in pairs (an image row per wave, the pair pools through the
+                    epilogue's LDS slab); anything else returns DH_EUNSUPPORTED */
 } dh_conv_args;
 
 /* padded dims of the packed weight for a [KH,KW,Cin,Cout] (Keras HWIO) kernel */

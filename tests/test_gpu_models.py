@@ -478,6 +478,26 @@ def test_hip_matches_real_keras_outputs(tag, hip_lib, cuda):
             assert float(np.max(np.abs(h - r))) <= 4 * PX_TOL, (tag, k)
 
 
+def test_pooled_epilogue_plan_is_bit_identical(hip_lib, cuda, monkeypatch):
+    """Planner rule R7 (MaxPooling2D written by the producing convolution's epilogue) changes no result bit, in either
+    GEMM mode."""
+    from deephar_amd.models import reception
+    for mode in ('f32', 'bf16x3'):
+        outs = {}
+        for fuse in ('1', '0'):
+            monkeypatch.setenv('DEEPHAR_FUSE_POOL', fuse)
+            m, _ = _build(2, 3, 16, num_context_per_joint=2)
+            m.gemm_precision = mode
+            x = np.random.default_rng(3).uniform(-1, 1, (3, 256, 256, 3)).astype(np.float32)
+            outs[fuse] = m.predict(x, batch_size=3)
+            n_pool = sum(1 for s in m.plan.steps if s.kind == 'pool' and s.ins['x'].shape[-2] == 32)
+            n_fused = sum(1 for s in m.plan.steps if s.kind == 'conv' and 'ypool' in s.outs)
+            assert (n_fused, n_pool) == ((3, 0) if fuse == '1' else (0, 3)), (mode, fuse, n_fused, n_pool)
+        monkeypatch.delenv('DEEPHAR_FUSE_POOL')
+        for a, b in zip(outs['1'], outs['0']):
+            assert np.array_equal(a, b), mode
+
+
 def test_keras_h5_weight_files_drive_the_gpu_model(hip_lib, cuda, tmp_path):
     """SURVEY.md 8f rank 1 on the GPU: a Keras-layout .h5 written by save_weights is loaded BY ORDER into a fresh
     ReceptionNet (eval_mpii_singleperson.py:54) and BY NAME into a fresh SPNet (eval_penn_multitask.py:76) whose weights

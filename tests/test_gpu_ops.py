@@ -522,6 +522,51 @@ SPLIT_CASES = [
 ]
 
 
+@pytest.mark.parametrize('case', [(3, 32, 32, 96, 200, 1, True, True, False), (2, 32, 32, 48, 576, 1, True, False, True),
+                                  (2, 64, 64, 64, 96, 3, False, True, False), (1, 6, 32, 288, 96, 1, False, False, False),
+                                  (2, 32, 32, 64, 100, 3, True, True, False)])
+def test_conv2d_pooled_second_output(case, hip_lib, cuda):
+    """dh_conv_args.y_pool: the epilogue also writes MaxPooling2D((2, 2)) of the final output.  Equal to pooling the
+    first output with the stand-alone kernel, for every tiling that takes it (fp32 general + DMA GEMM, split-bf16 incl.
+    its wide tiling, which runs the epilogue twice through one slab), with BN / residual / ReLU epilogues, two residuals, strided K x K producers and ragged channel tiles;
+    tilings without a wave pair, other widths and the up-sampling epilogue refuse it."""
+    from deephar_amd import functional as F
+    n, h, w, cin, cout, ks, relu, res, res2 = case
+    st = 2 if h == 64 else 1                                        # 64 x 64 input, stride 2 -> 32 x 32 output
+    rng = np.random.default_rng(sum(int(v) for v in case))
+    x = _rand(rng, (n, h, w, cin))
+    k = _rand(rng, (ks, ks, cin, cout), np.sqrt(1.0 / (ks * ks * cin)))
+    sc = rng.uniform(0.5, 1.5, cout).astype(np.float32)
+    sh = _rand(rng, (cout,), 0.1)
+    oh, ow = h // st, w // st
+    d = lambda a: None if a is None else torch.from_numpy(a).to(cuda)
+    r1 = _rand(rng, (n, oh, ow, cout)) if res else None
+    kw = dict(strides=(st, st), padding='same', pre_relu=relu, post_scale=d(sc), post_shift=d(sh), res1=d(r1), post_relu=res2)
+    base = F.conv2d(d(x), k, **kw)
+    ref_pool = F.pool2d(base, (2, 2))
+    took = {}
+    for split in (False, True):
+        ncfg = hip_lib.dh_conv2d_num_split_tile_cfgs() if split else hip_lib.dh_conv2d_num_tile_cfgs()
+        ref_y = F.conv2d(d(x), k, split=split, **kw)
+        for cfg in range(-1, ncfg):
+            try:
+                y, yp = F.conv2d(d(x), k, split=split, tile_cfg=cfg, pool2=True, **kw)
+            except Exception as e:
+                assert 'rc=-2' in str(e), e
+                continue
+            took[(split, cfg)] = True
+            assert torch.equal(y, ref_y), (split, cfg)
+            assert torch.equal(yp, F.pool2d(y, (2, 2))), (split, cfg)
+            if not split:
+                assert torch.equal(yp, ref_pool)
+    assert (False, -1) in took and (False, 11) in took and (False, 13) in took and (False, 2) in took
+    assert (False, 8) not in took and (False, 17) not in took and (False, 0) not in took      # no wave pair / 64-row waves
+    if cin % 32 == 0 or ks == 1:
+        assert (True, 14) in took and (True, 2) in took
+    with pytest.raises(Exception):                                                          # 16 columns: not built
+        F.conv2d(d(np.ascontiguousarray(x[:, :, :16 * st])), k, pool2=True, **dict(kw, res1=None))
+
+
 SKINNY_CASES = [
     # n, h, w, cin, cout, k, stride, bn prologue, relu, residual
     (4, 16, 16, 256, 256, 3, 1, False, True, False),     # merge action head: 3x3 over [T x J], K = 2304

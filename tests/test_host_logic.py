@@ -119,6 +119,7 @@ def test_planner_fusion_rules():
     kinds = [s.kind for s in plan.steps]
     # nothing but kernels that exist; BN / ReLU / add / concat / upsample never survive as their own launch
     assert set(kinds) <= {'conv', 'dwconv', 'pool', 'sam_ctx'}
+    assert sum(1 for s in plan.steps if s.kind == 'conv' and 'ypool' in s.outs) == 2          # R7: one per block
     convs = [s for s in plan.steps if s.kind == 'conv']
     # R3: both add([a, UpSampling2D(b)]) of every hourglass are second residuals, read at half resolution, of the
     # convolutions that produce `a`; those are emitted after the low-resolution branch that produces `b`
@@ -145,6 +146,32 @@ def test_planner_fusion_rules():
     # ... unless something else reads the intermediate coordinates: exported heat-maps do not, exported poses would
     kept = _mpii(1, num_context_per_joint=2, export_heatmaps=True).plan
     assert sum(1 for s in kept.steps if s.kind == 'sam_ctx') == 1
+
+
+def test_planner_pooled_output_rule(monkeypatch):
+    """R7: the 32-column MaxPooling2D becomes a second output of the convolution that feeds it; same algorithmic FLOPs,
+    one launch and one full-resolution read less per block, and the memory plan stays sound (DEEPHAR_FUSE_POOL=0: off)."""
+    monkeypatch.setenv('DEEPHAR_FUSE_POOL', '0')
+    base = _mpii(2).plan
+    monkeypatch.setenv('DEEPHAR_FUSE_POOL', '1')
+    plan = _mpii(2).plan
+    fused = [s for s in plan.steps if s.kind == 'conv' and 'ypool' in s.outs]
+    assert len(fused) == 2 and len(plan.steps) == len(base.steps) - 2
+    for s in fused:
+        y, yp = s.outs['y'], s.outs['ypool']
+        assert y.shape[-2] == 32 and yp.shape[-3:] == (y.shape[-3] // 2, 16, y.C) and s.attrs['pool2'] == 1
+    assert not any(s.kind == 'pool' and s.ins['x'].shape[-2] == 32 for s in plan.steps)
+    assert sum(s.flops() for s in plan.steps) == sum(s.flops() for s in base.steps)
+    assert sum(s.bytes() for s in plan.steps) < sum(s.bytes() for s in base.steps)
+    for i, s in enumerate(plan.steps):
+        for v in list(s.ins.values()) + list(s.outs.values()):
+            assert v.buf.start <= i <= v.buf.end
+    bufs = plan.bufs
+    for i, a in enumerate(bufs):
+        for b in bufs[i + 1:]:
+            live = not (a.end < b.start or b.end < a.start)
+            space = not (a.offset + a.items <= b.offset or b.offset + b.items <= a.offset)
+            assert not (live and space)
 
 
 def test_memory_plan_has_no_live_overlap():
