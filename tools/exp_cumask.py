@@ -18,15 +18,30 @@ def masked_stream(bits=None, priority=0):
     assert rc == 0, rc
     return st
 
+from deephar_amd.engine import schedule
+_default_assign = schedule.assign_streams
+
+
+def _lowres_assign(plan, deps, nstreams):
+    """every <= 16 x 16 map on stream 1, the rest on stream 0 (the experiment's 'lowres' policy)"""
+    if nstreams <= 1:
+        return _default_assign(plan, deps, nstreams)
+    stream = [0] * len(plan.steps)
+    for j, s in enumerate(plan.steps):
+        v = next(iter(s.outs.values()), None) if s.outs else None
+        if s.kind in ('conv', 'dwconv', 'pool') and v is not None and len(v.shape) >= 3 and \
+                v.shape[-3] * v.shape[-2] <= 256 and not s.attrs.get('up2'):
+            stream[j] = 1
+    return stream
+
+
 def build(policy, streams=2):
     import bench
-    if policy: os.environ['DEEPHAR_STREAM_POLICY'] = policy
-    else: os.environ.pop('DEEPHAR_STREAM_POLICY', None)
+    schedule.assign_streams = _lowres_assign if policy == 'lowres' else _default_assign
     m = bench.build_mpii(8)
     m.num_streams = streams
     ex = m.executor
     ex.use_graph = False
-    tc = os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', 'profiles', 'tune_mpii_b64.json')
     bp = ex.bind(64)
     x = np.random.default_rng(0).uniform(-1, 1, (64, 256, 256, 3)).astype(np.float32)
     with torch.cuda.stream(ex.stream):
