@@ -92,12 +92,12 @@ __global__ __launch_bounds__(256) void dwconv_kernel(const DwArgs p) {
 // ------------------------------------------------------------------------------------------------
 constexpr int DW_CQ = 8;        // channel quads per workgroup (32 channels)
 #ifndef DW_LDS_MIN_W
-#define DW_LDS_MIN_W 16
+#define DW_LDS_MIN_W 8
 #endif
 constexpr int DW_PITCH = 9;     // float4 per tile pixel (8 + 1 pad: spreads strips over LDS banks)
 
-template <int KS>
-__global__ __launch_bounds__(256) void dwconv_lds_kernel(const DwArgs p, const int tw, const int rows) {
+template <int KS, int NT, int MAXL>
+__global__ __launch_bounds__(NT) void dwconv_lds_kernel(const DwArgs p, const int tw, const int rows) {
   extern __shared__ __attribute__((aligned(16))) float4 dsm[];
   const int tid = threadIdx.x;
   const int chunks = p.C / 32;
@@ -114,7 +114,7 @@ __global__ __launch_bounds__(256) void dwconv_lds_kernel(const DwArgs p, const i
   const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
   const bool aff = p.pre_scale != nullptr;
 
-  for (int i = tid; i < KS * KS * DW_CQ; i += 256)
+  for (int i = tid; i < KS * KS * DW_CQ; i += NT)
     wts[i] = ld4(p.w + (size_t)(i / DW_CQ) * p.C + c0 + (i % DW_CQ) * 4);
   const int q_in = tid & (DW_CQ - 1);
   float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = zero;
@@ -123,15 +123,14 @@ __global__ __launch_bounds__(256) void dwconv_lds_kernel(const DwArgs p, const i
   // One work-group walks down the bands of its (frame, column tile, 32-channel chunk).  All global loads of a
   // band's halo tile are issued back to back (clamped addresses) into registers -- one HBM round trip per band,
   // not one per loop iteration -- and the loads of band t+1 are in flight while band t is computed from LDS.
-  constexpr int MAXL = 14;                          // ceil(12*36*8 / 256)
   float4 stage[MAXL];
   unsigned okmask = 0;
   auto fetch = [&](int band) {
     const int r0 = band * rows;
     okmask = 0;
 #pragma unroll
-    for (int j = 0; j < MAXL; ++j) {                // (tid + j*256) % 8 == tid % 8: the quad is fixed per thread
-      const int px = (tid + j * 256) / DW_CQ;
+    for (int j = 0; j < MAXL; ++j) {                // (tid + j*NT) % 8 == tid % 8: the quad is fixed per thread
+      const int px = (tid + j * NT) / DW_CQ;
       const int tr = px / twh, tc = px - tr * twh;
       const int ih = r0 - p.PT + tr, iw = w0 - p.PL + tc;
       const bool ok = px < npix && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
@@ -150,7 +149,7 @@ __global__ __launch_bounds__(256) void dwconv_lds_kernel(const DwArgs p, const i
     const int r0 = band * rows;
 #pragma unroll
     for (int j = 0; j < MAXL; ++j) {
-      const int px = (tid + j * 256) / DW_CQ;
+      const int px = (tid + j * NT) / DW_CQ;
       if (px >= npix) continue;
       float4 v = stage[j];
       if (aff) v = fma4(v, sc, sh);
@@ -361,16 +360,27 @@ int launch_dwconv(const DwArgs& a, hipStream_t s) {
   const bool vec = (a.C % 4 == 0) && (a.ldx % 4 == 0) && (a.ldy % 4 == 0) && al16(a.x) && al16(a.y) &&
                    al16(a.w) && (a.pre_scale == nullptr || (al16(a.pre_scale) && al16(a.pre_shift)));
   if (vec && a.KH == a.KW && (a.KW == 5 || a.KW == 3) && a.C % 32 == 0 && a.W >= DW_LDS_MIN_W && a.W % 8 == 0) {
-    // LDS-tiled path: column tile = min(W, 32), 8-column strips, rows chosen to fill 256 threads
+    // LDS-tiled path: column tile = min(W, 32), 8-column strips; the work-group is sized to the map --
+    //   W >= 32: 256 threads = 8 channel quads x 4 strips x 8 rows, bands of 8 rows walked inside the work-group
+    //   W == 16: 256 threads x 16 rows, one band (128 threads x 8 rows, two bands, 38 KB of LDS: 19.4 vs 18.0 us, not used)
+    //   W ==  8:  64 threads x  8 rows: the whole 8 x 8 map of a 32-channel chunk in one band (10.7 us; the register
+    //             kernel these maps ran on before took 13.0)
     const int tw = a.W >= 32 ? 32 : a.W;
-    int rows = 256 / (8 * (tw / 8));
+    const int nt = tw == 8 ? 64 : 256;
+    int rows = nt / (8 * (tw / 8));
     if (rows > a.H) rows = a.H;
     const long long blocks = (long long)a.N * ((a.W + tw - 1) / tw) * (a.C / 32);    // bands are walked inside
     const size_t lds = ((size_t)(rows + a.KW - 1) * (tw + a.KW - 1) * DW_PITCH + (size_t)a.KW * a.KW * DW_CQ) * 16;
-    if (blocks <= 0x7fffffffLL && lds <= 64 * 1024 &&
-        (rows + a.KW - 1) * (tw + a.KW - 1) * DW_CQ <= 14 * 256) {
-      if (a.KW == 5) hipLaunchKernelGGL(dwconv_lds_kernel<5>, dim3((unsigned)blocks), dim3(256), lds, s, a, tw, rows);
-      else hipLaunchKernelGGL(dwconv_lds_kernel<3>, dim3((unsigned)blocks), dim3(256), lds, s, a, tw, rows);
+    const int maxl = nt == 256 ? 14 : 18;
+    if (blocks <= 0x7fffffffLL && lds <= 64 * 1024 && (rows + a.KW - 1) * (tw + a.KW - 1) * DW_CQ <= maxl * nt) {
+      const dim3 g((unsigned)blocks);
+      if (a.KW == 5) {
+        if (nt == 256) hipLaunchKernelGGL((dwconv_lds_kernel<5, 256, 14>), g, dim3(256), lds, s, a, tw, rows);
+        else hipLaunchKernelGGL((dwconv_lds_kernel<5, 64, 18>), g, dim3(64), lds, s, a, tw, rows);
+      } else {
+        if (nt == 256) hipLaunchKernelGGL((dwconv_lds_kernel<3, 256, 14>), g, dim3(256), lds, s, a, tw, rows);
+        else hipLaunchKernelGGL((dwconv_lds_kernel<3, 64, 18>), g, dim3(64), lds, s, a, tw, rows);
+      }
       return check_launch();
     }
   }
