@@ -85,20 +85,58 @@ __global__ __launch_bounds__(256) void dwconv_kernel(const DwArgs p) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// LDS-tiled depthwise conv for the large maps (W >= 16, C % 32 == 0): workgroup = (image, band of rows,
-// 32-channel chunk, full-width column tile).  The halo'd input tile is fetched from global ONCE (prologue
-// affine / ReLU / zero padding applied on the way in), every one of the KSxKS re-reads comes from LDS, the
-// filter taps of the chunk sit in LDS too.  Thread = (channel quad, 8-column strip, row).
+// LDS-tiled depthwise conv (W >= 8, C % 32 == 0): workgroup = (image, 32-channel chunk, full-width column tile),
+// walking down bands of rows.  The halo'd input tile is fetched from global ONCE (prologue affine / ReLU / zero
+// padding applied on the way in), every one of the KSxKS re-reads comes from LDS, the filter taps of the chunk sit in
+// LDS too.  Thread = (channel quad, 8-column strip, row).
+//
+// The kernel is bound by VALU issue, not by HBM (round-3 instruction count: 400 packed FMAs per thread and band
+// against 530 other VALU instructions), so everything around the FMAs is kept off the vector ALU:
+//   * loads are buffer loads through a descriptor over ONE frame: per-slot byte offsets are computed once, a band
+//     costs one v_add per load, and rows above / below the frame and halo columns left / right of it are out-of-range
+//     offsets -- the load returns zeros, which is the padding (after ReLU; the affine variant masks explicitly);
+//   * LDS tile addresses are computed once per thread (slots beyond the tile write one dump cell, unpredicated);
+//   * stores are buffer stores with the column step in the scalar offset.
 // ------------------------------------------------------------------------------------------------
 constexpr int DW_CQ = 8;        // channel quads per workgroup (32 channels)
 #ifndef DW_LDS_MIN_W
 #define DW_LDS_MIN_W 8
 #endif
 constexpr int DW_PITCH = 9;     // float4 per tile pixel (8 + 1 pad: spreads strips over LDS banks)
+constexpr int DW_OOB = (int)0x80000000u;   // + any band offset (< 2 GB, checked at launch) stays out of range
 
-template <int KS, int NT, int MAXL>
-__global__ __launch_bounds__(NT) void dwconv_lds_kernel(const DwArgs p, const int tw, const int rows) {
+typedef unsigned int dw_u4 __attribute__((ext_vector_type(4)));
+template <typename RSRC>
+__device__ __forceinline__ float4 buf_ld4(RSRC rs, int voff) {
+  float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
+#if defined(__HIP_DEVICE_COMPILE__)
+  const dw_u4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, 0, 0);
+  r = make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+#endif
+  return r;
+}
+template <typename RSRC>
+__device__ __forceinline__ void buf_st4(RSRC rs, int voff, int soff, float4 r) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  dw_u4 v;
+  v.x = __float_as_uint(r.x); v.y = __float_as_uint(r.y); v.z = __float_as_uint(r.z); v.w = __float_as_uint(r.w);
+  __builtin_amdgcn_raw_buffer_store_b128(v, rs, voff, soff, 0);
+#endif
+}
+// relu as one integer max per element (see gemm1x1.hip: relu1)
+__device__ __forceinline__ float dw_relu1(float v) {
+  const int b = __float_as_int(v);
+  return __int_as_float(b > 0 ? b : 0);
+}
+__device__ __forceinline__ float4 dw_relu4(float4 v) {
+  return make_float4(dw_relu1(v.x), dw_relu1(v.y), dw_relu1(v.z), dw_relu1(v.w));
+}
+
+// MAXT / MAXN: load slots per thread for the KS - 1 rows above the first band / for the `rows` new rows of a band
+template <int KS, int NT, int MAXT, int MAXN, bool AFF, bool RELU>
+__global__ __launch_bounds__(NT) void dwconv_lds_kernel(const DwArgs p, const int tw, const int rows, const int twh_magic) {
   extern __shared__ __attribute__((aligned(16))) float4 dsm[];
+  constexpr int SP = NT / DW_CQ;                    // tile pixels per load slot
   const int tid = threadIdx.x;
   const int chunks = p.C / 32;
   const int bands = (p.H + rows - 1) / rows;
@@ -109,53 +147,96 @@ __global__ __launch_bounds__(NT) void dwconv_lds_kernel(const DwArgs p, const in
   const int n = b / ctiles;
   const int c0 = cchunk * 32, w0 = ct * tw;
   const int th = rows + KS - 1, twh = tw + KS - 1;
-  float4* tile = dsm;                               // [th][twh][DW_PITCH]
-  float4* wts = dsm + th * twh * DW_PITCH;          // [KS*KS][DW_CQ]
+  float4* wts = dsm;                                // [KS*KS][DW_CQ]
+  float4* tile = dsm + KS * KS * DW_CQ;             // ring of th rows: [th][twh][DW_PITCH], + one dump cell
   const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
-  const bool aff = p.pre_scale != nullptr;
 
   for (int i = tid; i < KS * KS * DW_CQ; i += NT)
     wts[i] = ld4(p.w + (size_t)(i / DW_CQ) * p.C + c0 + (i % DW_CQ) * 4);
-  const int q_in = tid & (DW_CQ - 1);
+  const int q = tid & (DW_CQ - 1);
   float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = zero;
-  if (aff) { sc = ld4(p.pre_scale + c0 + q_in * 4); sh = ld4(p.pre_shift + c0 + q_in * 4); }
-  const int npix = th * twh;
-  // One work-group walks down the bands of its (frame, column tile, 32-channel chunk).  All global loads of a
-  // band's halo tile are issued back to back (clamped addresses) into registers -- one HBM round trip per band,
-  // not one per loop iteration -- and the loads of band t+1 are in flight while band t is computed from LDS.
-  float4 stage[MAXL];
-  unsigned okmask = 0;
-  auto fetch = [&](int band) {
-    const int r0 = band * rows;
-    okmask = 0;
+  if constexpr (AFF) { sc = ld4(p.pre_scale + c0 + q * 4); sh = ld4(p.pre_shift + c0 + q * 4); }
+
+  const auto rs_x = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(p.x) + (size_t)n * p.H * p.W * p.ldx, 0,
+      (int)(((unsigned)(p.H * p.W - 1) * p.ldx + (unsigned)p.C) * 4u), 0x00020000);
+  const auto rs_y = __builtin_amdgcn_make_buffer_rsrc(
+      p.y + (size_t)n * p.H * p.W * p.ldy, 0, (int)(((unsigned)(p.H * p.W - 1) * p.ldy + (unsigned)p.C) * 4u), 0x00020000);
+  const int row_bytes = twh * DW_PITCH * 16, ring_bytes = th * row_bytes;
+  const int dump = ring_bytes;                      // byte offset (from `tile`) of the cell that swallows unused slots
+  // px / twh for px < 1024 as multiply + shift (twh_magic = 65536 / twh + 1): an integer divide is ~40 VALU instructions
+  auto row_of = [&](int px) { return (px * twh_magic) >> 16; };
+  auto px_offset = [&](int px, int first_row) {     // frame byte offset of window pixel px, window starting at first_row
+    const int tr = row_of(px), tc = px - tr * twh;
+    const int iw = w0 - p.PL + tc;
+    return (unsigned)iw < (unsigned)p.W ? (((first_row + tr) * p.W + iw) * p.ldx + c0 + q * 4) * 4 : DW_OOB;
+  };
+
+  // ---- the KS - 1 rows above the first band (input rows -PT .. KS - 2 - PT) go to ring rows 0 .. KS - 2, once
+  {
+    float4 top[MAXT];
 #pragma unroll
-    for (int j = 0; j < MAXL; ++j) {                // (tid + j*NT) % 8 == tid % 8: the quad is fixed per thread
-      const int px = (tid + j * NT) / DW_CQ;
-      const int tr = px / twh, tc = px - tr * twh;
-      const int ih = r0 - p.PT + tr, iw = w0 - p.PL + tc;
-      const bool ok = px < npix && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
-      const size_t off = ok ? ((size_t)(n * p.H + ih) * p.W + iw) * p.ldx + c0 + q_in * 4 : 0;
-      stage[j] = ld4(p.x + off);
-      okmask |= (ok ? 1u : 0u) << j;
+    for (int j = 0; j < MAXT; ++j) {
+      const int px = (tid >> 3) + j * SP;
+      top[j] = buf_ld4(rs_x, px < (KS - 1) * twh ? px_offset(px, -p.PT) : DW_OOB);
     }
+#pragma unroll
+    for (int j = 0; j < MAXT; ++j) {
+      const int px = (tid >> 3) + j * SP;
+      float4 v = top[j];
+      if constexpr (AFF) {
+        const int tr = row_of(px), iw = w0 - p.PL + px - tr * twh;
+        v = fma4(v, sc, sh);
+        if (!((unsigned)(tr - p.PT) < (unsigned)p.H && (unsigned)iw < (unsigned)p.W)) v = zero;
+      }
+      if constexpr (RELU) v = dw_relu4(v);
+      if (px < (KS - 1) * twh) tile[px * DW_PITCH + q] = v;
+    }
+  }
+  // ---- every band then brings in only its `rows` NEW rows (window rows KS - 1 .. th - 1 = input rows r0 + KS - 1 - PT
+  // ...): the KS - 1 rows it shares with the band above stay where they are.  Input row i lives in ring row (i + PT) % th.
+  // Slot j of this thread = pixel (tid >> 3) + j * SP of the new-row window, quad q; its frame offset for band 0 and its
+  // ring offset for band 0 are computed once, a band adds one scalar to each (and wraps the ring offset).
+  int voff[MAXN], loff[MAXN];
+  int trow[AFF ? MAXN : 1];                           // affine variant: the slot's window row, -1 = never valid
+#pragma unroll
+  for (int j = 0; j < MAXN; ++j) {
+    const int px = (tid >> 3) + j * SP;
+    const bool in = px < rows * twh;
+    voff[j] = in ? px_offset(px, KS - 1 - p.PT) : DW_OOB;
+    loff[j] = in ? (KS - 1) * row_bytes + (px * DW_PITCH + q) * 16 : -1;
+    if constexpr (AFF) trow[j] = (in && voff[j] != DW_OOB) ? row_of(px) : -1;
+  }
+  float4 stage[MAXN];
+  auto fetch = [&](int band) {                      // issued back to back: one round trip per band, in flight while
+    const int boff = band * rows * p.W * p.ldx * 4;  // the previous band is computed from LDS
+#pragma unroll
+    for (int j = 0; j < MAXN; ++j) stage[j] = buf_ld4(rs_x, voff[j] + boff);
   };
   const int strips = tw >> 3;
-  const int q = tid & (DW_CQ - 1);
   const int strip = (tid >> 3) % strips;
   const int row = (tid >> 3) / strips;
+  const int y_off = ((row * p.W + w0 + strip * 8) * p.ldy + c0 + q * 4) * 4;
+  const int y_col = p.ldy * 4;
+  char* const tile_b = reinterpret_cast<char*>(tile);
 
   fetch(0);
+  int ring0 = 0;                                    // ring row of this band's window row 0 (= r0 % th)
   for (int band = 0; band < bands; ++band) {
     const int r0 = band * rows;
+    const int shift = ring0 * row_bytes;
 #pragma unroll
-    for (int j = 0; j < MAXL; ++j) {
-      const int px = (tid + j * NT) / DW_CQ;
-      if (px >= npix) continue;
+    for (int j = 0; j < MAXN; ++j) {
       float4 v = stage[j];
-      if (aff) v = fma4(v, sc, sh);
-      if (p.pre_relu) v = max4(v, zero);
-      if (!((okmask >> j) & 1u)) v = zero;
-      tile[px * DW_PITCH + q_in] = v;
+      if constexpr (AFF) {
+        v = fma4(v, sc, sh);
+        if (!(trow[j] >= 0 && (unsigned)(r0 + KS - 1 - p.PT + trow[j]) < (unsigned)p.H)) v = zero;   // pad AFTER the affine
+      }
+      if constexpr (RELU) v = dw_relu4(v);
+      int o = loff[j] + shift;
+      o = o >= ring_bytes ? o - ring_bytes : o;
+      o = loff[j] < 0 ? dump : o;
+      *reinterpret_cast<float4*>(tile_b + o) = v;
     }
     __syncthreads();
     if (band + 1 < bands) fetch(band + 1);
@@ -164,12 +245,14 @@ __global__ __launch_bounds__(NT) void dwconv_lds_kernel(const DwArgs p, const in
       float4 acc[8];
 #pragma unroll
       for (int i = 0; i < 8; ++i) acc[i] = zero;
+      int rr = ring0 + row;                          // ring row of window row (row + kh)
+      rr = rr >= th ? rr - th : rr;
 #pragma unroll 1                                   // one kernel row of LDS reads in flight: keeps 2+ waves per SIMD
       for (int kh = 0; kh < KS; ++kh) {
         float4 wv[KS];
 #pragma unroll
         for (int kw = 0; kw < KS; ++kw) wv[kw] = wts[(kh * KS + kw) * DW_CQ + q];
-        const float4* src = tile + ((row + kh) * twh + strip * 8) * DW_PITCH + q;
+        const float4* src = tile + (rr * twh + strip * 8) * DW_PITCH + q;
 #pragma unroll
         for (int j = 0; j < 8 + KS - 1; ++j) {
           const float4 v = src[j * DW_PITCH];
@@ -179,14 +262,15 @@ __global__ __launch_bounds__(NT) void dwconv_lds_kernel(const DwArgs p, const in
             if (o >= 0 && o < 8) acc[o] = fma4(v, wv[kw], acc[o]);
           }
         }
+        rr = rr + 1 == th ? 0 : rr + 1;
       }
-      const int ow0 = w0 + strip * 8;
-      float* out = p.y + ((size_t)(n * p.H + r0 + row) * p.W + ow0) * p.ldy + c0 + q * 4;
+      const int yo = y_off + r0 * p.W * p.ldy * 4;
 #pragma unroll
-      for (int i = 0; i < 8; ++i)
-        if (ow0 + i < p.W) st4(out + (size_t)i * p.ldy, acc[i]);
+      for (int i = 0; i < 8; ++i) buf_st4(rs_y, yo, i * y_col, acc[i]);     // W % 8 == 0: every strip is whole
     }
-    __syncthreads();                                // every wave is done reading the tile before it is refilled
+    __syncthreads();                                // every wave is done reading the rows the next band overwrites
+    ring0 += rows;
+    ring0 = ring0 >= th ? ring0 - th : ring0;
   }
 }
 
@@ -353,6 +437,39 @@ inline unsigned grid_for(long long total, int block = 256) {
 
 inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
+template <int KS, int NT, int MAXT, int MAXN, bool AFF, bool RELU>
+int launch_dw_lds_variant(const DwArgs& a, int tw, int rows, unsigned blocks, size_t lds, hipStream_t s) {
+  auto kern = dwconv_lds_kernel<KS, NT, MAXT, MAXN, AFF, RELU>;
+  if (lds > 64 * 1024) {
+    static bool once = (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds),
+                        true);
+    (void)once;
+  }
+  hipLaunchKernelGGL(kern, dim3(blocks), dim3(NT), lds, s, a, tw, rows, 65536 / (tw + KS - 1) + 1);
+  return check_launch();
+}
+
+template <int KS, int NT, int MAXT, int MAXN>
+int launch_dw_lds_ks(const DwArgs& a, int tw, int rows, unsigned blocks, size_t lds, hipStream_t s) {
+  const int twh = tw + KS - 1;
+  if ((KS - 1) * twh > MAXT * (NT / DW_CQ) || rows * twh > MAXN * (NT / DW_CQ)) return DH_EUNSUPPORTED;
+  const bool aff = a.pre_scale != nullptr;
+  if (aff) return a.pre_relu ? launch_dw_lds_variant<KS, NT, MAXT, MAXN, true, true>(a, tw, rows, blocks, lds, s)
+                             : launch_dw_lds_variant<KS, NT, MAXT, MAXN, true, false>(a, tw, rows, blocks, lds, s);
+  return a.pre_relu ? launch_dw_lds_variant<KS, NT, MAXT, MAXN, false, true>(a, tw, rows, blocks, lds, s)
+                    : launch_dw_lds_variant<KS, NT, MAXT, MAXN, false, false>(a, tw, rows, blocks, lds, s);
+}
+
+int launch_dw_lds(const DwArgs& a, int tw, int rows, int nt, unsigned blocks, size_t lds, hipStream_t s) {
+  // slots per thread: 256 threads = 32 tile pixels per slot (5 x 36-pixel rows above, 8 x 36 or 16 x 20 new pixels per
+  // band), 64 threads = 8 pixels per slot (4 x 12 above, 8 x 12 new)
+  if (a.KW == 5) return nt == 256 ? launch_dw_lds_ks<5, 256, 5, 10>(a, tw, rows, blocks, lds, s)
+                                  : launch_dw_lds_ks<5, 64, 6, 12>(a, tw, rows, blocks, lds, s);
+  return nt == 256 ? launch_dw_lds_ks<3, 256, 3, 10>(a, tw, rows, blocks, lds, s)
+                   : launch_dw_lds_ks<3, 64, 3, 10>(a, tw, rows, blocks, lds, s);
+}
+
+
 }  // namespace
 
 int launch_dwconv(const DwArgs& a, hipStream_t s) {
@@ -370,18 +487,11 @@ int launch_dwconv(const DwArgs& a, hipStream_t s) {
     int rows = nt / (8 * (tw / 8));
     if (rows > a.H) rows = a.H;
     const long long blocks = (long long)a.N * ((a.W + tw - 1) / tw) * (a.C / 32);    // bands are walked inside
-    const size_t lds = ((size_t)(rows + a.KW - 1) * (tw + a.KW - 1) * DW_PITCH + (size_t)a.KW * a.KW * DW_CQ) * 16;
-    const int maxl = nt == 256 ? 14 : 18;
-    if (blocks <= 0x7fffffffLL && lds <= 64 * 1024 && (rows + a.KW - 1) * (tw + a.KW - 1) * DW_CQ <= maxl * nt) {
-      const dim3 g((unsigned)blocks);
-      if (a.KW == 5) {
-        if (nt == 256) hipLaunchKernelGGL((dwconv_lds_kernel<5, 256, 14>), g, dim3(256), lds, s, a, tw, rows);
-        else hipLaunchKernelGGL((dwconv_lds_kernel<5, 64, 18>), g, dim3(64), lds, s, a, tw, rows);
-      } else {
-        if (nt == 256) hipLaunchKernelGGL((dwconv_lds_kernel<3, 256, 14>), g, dim3(256), lds, s, a, tw, rows);
-        else hipLaunchKernelGGL((dwconv_lds_kernel<3, 64, 18>), g, dim3(64), lds, s, a, tw, rows);
-      }
-      return check_launch();
+    const size_t lds = ((size_t)(rows + a.KW - 1) * (tw + a.KW - 1) * DW_PITCH + (size_t)a.KW * a.KW * DW_CQ + 1) * 16;
+    const bool fits31 = (long long)a.H * a.W * a.ldx * 4 < 0x7fffffffLL && (long long)a.H * a.W * a.ldy * 4 < 0x7fffffffLL;
+    if (blocks <= 0x7fffffffLL && fits31) {
+      const int rc = launch_dw_lds(a, tw, rows, nt, (unsigned)blocks, lds, s);
+      if (rc != DH_EUNSUPPORTED) return rc;
     }
   }
   if (vec && a.KH == a.KW && (a.KW == 5 || a.KW == 3 || a.KW == 1)) {

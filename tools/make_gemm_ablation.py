@@ -34,7 +34,8 @@ variants = {
 }
 os.makedirs(os.path.join(ROOT, 'tools/ab'), exist_ok=True)
 for name, text in variants.items():
-    path = '/tmp/gemm1x1_%s.hip' % name
+    os.makedirs('/tmp/ab_src', exist_ok=True)
+    path = '/tmp/ab_src/gemm1x1_%s.hip' % name   # a directory of its own: a stray header next to the source would shadow -I
     open(path, 'w').write(text)
     subprocess.run([sys.executable, os.path.join(ROOT, 'tools/build_variant.py'), path,
                     os.path.join(ROOT, 'tools/ab/lib_%s.so' % name)], check=True)
