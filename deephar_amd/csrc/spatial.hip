@@ -207,9 +207,14 @@ __global__ __launch_bounds__(NT) void dwconv_lds_kernel(const DwArgs p, const in
     loff[j] = in ? (KS - 1) * row_bytes + (px * DW_PITCH + q) * 16 : -1;
     if constexpr (AFF) trow[j] = (in && voff[j] != DW_OOB) ? row_of(px) : -1;
   }
+  // The loads of a band are issued back to back (one round trip per band) and are NOT overlapped with the previous
+  // band's arithmetic: with the next band in flight during the FMAs the kernel is 6 % faster in isolation (62 vs 66 us on
+  // 64 x 32 x 32 x 576), but on most boxes of the pool the firmware then drops the engine clock of the WHOLE forward by
+  // 5 % (2213 vs 2338 MHz; the GEMMs lose 6 %, the step 4 %) -- profiles/r03_dvfs_study.md.  The other work-group of the
+  // CU covers the wait.
   float4 stage[MAXN];
-  auto fetch = [&](int band) {                      // issued back to back: one round trip per band, in flight while
-    const int boff = band * rows * p.W * p.ldx * 4;  // the previous band is computed from LDS
+  auto fetch = [&](int band) {
+    const int boff = band * rows * p.W * p.ldx * 4;
 #pragma unroll
     for (int j = 0; j < MAXN; ++j) stage[j] = buf_ld4(rs_x, voff[j] + boff);
   };
@@ -220,11 +225,11 @@ __global__ __launch_bounds__(NT) void dwconv_lds_kernel(const DwArgs p, const in
   const int y_col = p.ldy * 4;
   char* const tile_b = reinterpret_cast<char*>(tile);
 
-  fetch(0);
   int ring0 = 0;                                    // ring row of this band's window row 0 (= r0 % th)
   for (int band = 0; band < bands; ++band) {
     const int r0 = band * rows;
     const int shift = ring0 * row_bytes;
+    fetch(band);
 #pragma unroll
     for (int j = 0; j < MAXN; ++j) {
       float4 v = stage[j];
@@ -239,9 +244,8 @@ __global__ __launch_bounds__(NT) void dwconv_lds_kernel(const DwArgs p, const in
       *reinterpret_cast<float4*>(tile_b + o) = v;
     }
     __syncthreads();
-    if (band + 1 < bands) fetch(band + 1);
 
-    if (row < rows && r0 + row < p.H) {
+    if (row < rows && r0 + row < p.H && w0 + strip * 8 < p.W) {   // (W % 8 == 0: a strip is inside the frame or outside)
       float4 acc[8];
 #pragma unroll
       for (int i = 0; i < 8; ++i) acc[i] = zero;
@@ -266,7 +270,7 @@ __global__ __launch_bounds__(NT) void dwconv_lds_kernel(const DwArgs p, const in
       }
       const int yo = y_off + r0 * p.W * p.ldy * 4;
 #pragma unroll
-      for (int i = 0; i < 8; ++i) buf_st4(rs_y, yo, i * y_col, acc[i]);     // W % 8 == 0: every strip is whole
+      for (int i = 0; i < 8; ++i) buf_st4(rs_y, yo, i * y_col, acc[i]);
     }
     __syncthreads();                                // every wave is done reading the rows the next band overwrites
     ring0 += rows;

@@ -157,8 +157,13 @@ def test_conv2d_fused_upsample_add(cout, cfg, hip_lib, cuda):
 
 @pytest.mark.parametrize('shape,k', [((2, 32, 32, 576), 5), ((3, 16, 16, 288), 5), ((2, 8, 8, 288), 5),
                                      ((2, 32, 32, 384), 3), ((1, 7, 9, 20), 5), ((2, 5, 6, 6), 3),
-                                     ((2, 16, 16, 16), 1)])
+                                     ((2, 16, 16, 16), 1),
+                                     # the row ring of the LDS kernel: many bands, two column tiles, a last band of 4 rows,
+                                     # a map lower than one band, a column tile that is half outside the frame
+                                     ((2, 64, 64, 64), 5), ((1, 64, 64, 32), 3), ((1, 44, 32, 32), 5), ((2, 4, 32, 32), 5),
+                                     ((1, 24, 48, 64), 5), ((1, 20, 128, 32), 3), ((3, 128, 128, 32), 5)])
 def test_dwconv(shape, k, hip_lib, cuda):
+    """Depthwise conv vs the oracle, three prologues (none, ReLU, BatchNorm + ReLU with the zero padding applied after it)."""
     from deephar_amd import functional as F
     rng = np.random.default_rng(shape[3] + k)
     x = _rand(rng, shape)
