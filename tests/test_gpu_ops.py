@@ -177,6 +177,31 @@ def test_dwconv(shape, k, hip_lib, cuda):
            O.depthwise_conv2d(O.relu(t(x) * t(ps) + t(pb)), t(dw)), atol=1e-5, what='dw bn relu')
 
 
+@pytest.mark.parametrize('h,w,c,k', [(32, 32, 64, 5), (16, 16, 32, 5), (8, 8, 32, 3), (40, 64, 32, 3)])
+def test_dwconv_on_channel_slabs(h, w, c, k, hip_lib, cuda):
+    """The planner hands the depthwise kernel views into wider tensors (concat slabs): ldx, ldy > C and a channel offset.
+    The buffer descriptors of the LDS kernel are sized from ld, not from C; nothing outside the slab may be touched."""
+    import ctypes as C
+    from deephar_amd import _lib
+    from deephar_amd.layers import same_pad
+    rng = np.random.default_rng(h + w + c + k)
+    n, cx, cy, ox, oy = 3, 3 * c, 3 * c, c, 2 * c              # input slab [c, 2c), output slab [2c, 3c) of 3c-channel tensors
+    xf = torch.from_numpy(_rand(rng, (n, h, w, cx))).to(cuda)
+    yf = torch.full((n, h, w, cy), 7.0, device=cuda)
+    dw = _rand(rng, (k, k, c, 1), 1.0 / k)
+    wt = torch.from_numpy(np.ascontiguousarray(dw.reshape(k * k, c))).to(cuda)
+    a = _lib.DwArgs()
+    a.x, a.w, a.y = xf.data_ptr() + 4 * ox, wt.data_ptr(), yf.data_ptr() + 4 * oy
+    a.N, a.H, a.W, a.C, a.ldx, a.ldy = n, h, w, c, cx, cy
+    a.KH = a.KW = k
+    a.PT, a.PL, a.pre_relu = same_pad(h, k, 1)[0], same_pad(w, k, 1)[0], 1
+    _lib.check(hip_lib.dh_dwconv2d_f32(C.byref(a), torch.cuda.current_stream().cuda_stream), 'dw slab')
+    torch.cuda.synchronize()
+    ref = O.depthwise_conv2d(O.relu(xf[..., ox:ox + c].cpu()), torch.from_numpy(dw))
+    _close(yf[..., oy:oy + c], ref, atol=1e-5, what='dw slab')
+    assert torch.all(yf[..., :oy] == 7.0) and torch.all(yf[..., oy + c:] == 7.0), 'wrote outside its channel slab'
+
+
 @pytest.mark.parametrize('shape,pool,strides,pad', [
     ((2, 128, 128, 64), (3, 3), (2, 2), 'same'), ((2, 64, 64, 192), (2, 2), (2, 2), 'valid'),
     ((2, 32, 32, 576), (2, 2), None, 'valid'), ((2, 16, 17, 30), (2, 2), (2, 2), 'same'),
