@@ -1,6 +1,8 @@
 // Shared pieces of the two MFMA convolution kernels (conv_igemm.hip: general implicit GEMM with register
 // staging; gemm1x1.hip: pointwise GEMM with LDS-DMA double buffering).
 #pragma once
+#include <type_traits>
+
 #include "dh_kernels.h"
 
 namespace dh {
@@ -18,6 +20,36 @@ __device__ __forceinline__ void st4_stream(float* ptr, float4 v) {
 __device__ __forceinline__ float4 ld4_stream(const float* ptr) {
   const f32x4v t = __builtin_nontemporal_load(reinterpret_cast<const f32x4v*>(ptr));
   return make_float4(t.x, t.y, t.z, t.w);
+}
+
+// Streaming dword accesses through a buffer descriptor: per-lane byte offset in a VGPR, the wave-uniform part of the
+// address in the SCALAR offset -- an access costs no vector-ALU address arithmetic.  aux = 2: non-temporal.
+// (The builtins only exist in the device pass.)
+template <typename RSRC>
+__device__ __forceinline__ float buf_ld1_stream(RSRC rs, int voff, int soff) {
+  float r = 0.f;
+#if defined(__HIP_DEVICE_COMPILE__)
+  r = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, voff, soff, 2));
+#endif
+  return r;
+}
+template <typename RSRC>
+__device__ __forceinline__ void buf_st1_stream(RSRC rs, int voff, int soff, float v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rs, voff, soff, 2);
+#endif
+}
+__device__ __forceinline__ float& f4c(float4& v, int c) { return c == 0 ? v.x : c == 1 ? v.y : c == 2 ? v.z : v.w; }
+__device__ __forceinline__ float f4c(const float4& v, int c) { return c == 0 ? v.x : c == 1 ? v.y : c == 2 ? v.z : v.w; }
+
+// Launch-side half of the direct epilogue: `epi` (1 = 16-byte epilogue possible) gains bit 1 when interior tiles may
+// store straight from the accumulators -- no up-sampling, no pooled second output, one residual at most, and every
+// byte offset of y / res1 inside 31 bits (buffer offsets are 32-bit).
+inline int epi_with_direct(const ConvArgs& a, int epi) {
+  const long long M = (long long)a.N * a.OH * a.OW;
+  const bool direct = epi && !a.up2 && a.y_pool == nullptr && a.res2 == nullptr && M * a.ldy * 4 < 0x7fffffffLL &&
+                      (a.res1 == nullptr || M * a.ldr1 * 4 < 0x7fffffffLL);
+  return epi | (direct ? 2 : 0);
 }
 
 // XCD-aware bijective remap: block b runs on XCD b%8; give each XCD a contiguous run of tiles so the
@@ -51,10 +83,41 @@ struct EpiPrefetch {
   // (128x32 .. 128x96 per work-group) have them to spare
   static constexpr bool kEnabled = (TM == 1);
   float4 r1[kEnabled ? TM : 1][kEnabled ? IT : 1];
+  float dsc[kEnabled ? TN : 1], dsh[kEnabled ? TN : 1];   // direct epilogue: this lane's BN scale / shift per column tile
+
+  // epi_vec bit 1 (set by the launcher: no up-sampling, no pooled output, one residual at most, 31-bit offsets) + a tile
+  // that lies fully inside the output: the epilogue runs straight from the accumulators (conv_epilogue, direct path)
+  template <int WM, int WN>
+  static __device__ __forceinline__ bool direct_tile(const ConvArgs& p, int m0, int n0, int M, int epi_vec) {
+    return (epi_vec & 2) != 0 && m0 + WM * TM * 32 <= M && n0 + WN * TN * 32 <= p.Cout;
+  }
 
   template <int WM, int WN>
   __device__ __forceinline__ void issue(const ConvArgs& p, int m0, int n0, int M, int epi_vec) {
     if constexpr (kEnabled) {
+      if (direct_tile<WM, WN>(p, m0, n0, M, epi_vec)) {
+        // accumulator layout: register r of lane (li, lh) is row (r & 3) + 8 * (r >> 2) + 4 * lh, column li of the tile
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        const int wm = wave / WN, wn = wave % WN;
+        const int li = lane & 31, lh = lane >> 5;
+        const int ncol = n0 + wn * TN * 32 + li;
+        if (p.post_scale != nullptr) {
+#pragma unroll
+          for (int j = 0; j < TN; ++j) { dsc[j] = p.post_scale[ncol + j * 32]; dsh[j] = p.post_shift[ncol + j * 32]; }
+        }
+        if (p.res1 == nullptr) return;
+        const auto rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.res1), 0,
+                                                          (int)(((unsigned)(M - 1) * p.ldr1 + (unsigned)p.Cout) * 4u), 0x00020000);
+        const int vo = ((m0 + wm * TM * 32 + 4 * lh) * p.ldr1 + ncol) * 4;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+              f4c(r1[i][j * 4 + (r >> 2)], r & 3) = buf_ld1_stream(rs, vo, ((i * 32 + (r & 3) + 8 * (r >> 2)) * p.ldr1 + j * 32) * 4);
+        return;
+      }
       if (epi_vec == 0 || p.res1 == nullptr) return;
       const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
       const int wm = wave / WN, wn = wave % WN;
@@ -101,6 +164,36 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x16 (&acc)[T
   constexpr int NSC = (64 % ROW4 == 0) ? 1 : 3;   // distinct column groups a lane meets over the row loop
   constexpr bool kPre = PRE && EpiPrefetch<TM, TN>::kEnabled;
   constexpr bool kPool = conv_epilogue_pools<WM, TM, UP2>();
+  if constexpr (!UP2 && kPre && std::is_same<HOOK, EpiNoHook>::value) {
+    if (EpiPrefetch<TM, TN>::template direct_tile<WM, WN>(p, m0, n0, M, epi_vec)) {
+      // Direct path (interior tiles of plain launches): no LDS staging, no work-group barrier, no wait between the last
+      // MFMA and the first store.  Register r of a lane is one row of one column: a store instruction writes two
+      // 128-byte row segments, BN scale / shift are one value per lane and column tile, the row step is a scalar offset.
+      const auto rs_y = __builtin_amdgcn_make_buffer_rsrc(p.y, 0, (int)(((unsigned)(M - 1) * p.ldy + (unsigned)p.Cout) * 4u),
+                                                          0x00020000);
+      const int ncol = n0 + wn * TN * 32 + li;
+      const int vo = ((m0 + wm * TM * 32 + 4 * lh) * p.ldy + ncol) * 4;
+      float sc[TN], sh[TN];
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        sc[j] = pre.dsc[j];
+        sh[j] = pre.dsh[j];
+      }
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            float t = acc[i][j][r];
+            if (p.post_scale != nullptr) t = t * sc[j] + sh[j];
+            if (p.res1 != nullptr) t += f4c(pre.r1[i][j * 4 + (r >> 2)], r & 3);
+            if (p.post_relu) t = fmaxf(t, 0.f);
+            buf_st1_stream(rs_y, vo, ((i * 32 + (r & 3) + 8 * (r >> 2)) * p.ldy + j * 32) * 4, t);
+          }
+      return;
+    }
+  }
   float* sC = smem + wave * 32 * LDC;
   const int ohw = p.OH * p.OW;
   const bool vec = epi_vec != 0;

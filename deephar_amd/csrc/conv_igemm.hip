@@ -327,7 +327,7 @@ int launch_conv_igemm(const ConvArgs& a, int cfg, hipStream_t s) {
                   (a.res2 == nullptr || (a.ldr2 % 4 == 0 && al16(a.res2))) &&
                   (a.post_scale == nullptr || (al16(a.post_scale) && al16(a.post_shift)));
   if (a.y_pool != nullptr && !epi) return DH_EUNSUPPORTED;
-  if (a.w_split == 2) return launch_conv_halo(a, cfg, epi, s);   // chunk-major fp32 packing: the halo-resident kernel only
+  if (a.w_split == 2) return launch_conv_halo(a, cfg, epi_with_direct(a, epi), s);   // chunk-major fp32 packing: the halo-resident kernel only
   if (cfg < 0 && a.y_pool != nullptr) {
     cfg = conv_igemm_pick_cfg(a.N * a.OH * a.OW, a.Cout);
     if (cfg == 8) cfg = 7;                // 32 x 32 has no wave pair
@@ -347,7 +347,7 @@ int launch_conv_igemm(const ConvArgs& a, int cfg, hipStream_t s) {
   if (cfg >= kNumCfgs) {
     cfg -= kNumCfgs;
     if (a.up2 && cfg == 0) cfg = 2;
-    return launch_gemm1x1(a, cfg, epi, s);
+    return launch_gemm1x1(a, cfg, epi_with_direct(a, epi), s);   // interior tiles: epilogue straight from the accumulators
   }
   if (a.up2 && cfg == 0) cfg = 2;  // 128x192 + fused up-sampling epilogue exceeds the register budget
   const bool vec4 = !a.x_u8 && (a.Cin % 4 == 0) && (a.ldx % 4 == 0) && ((reinterpret_cast<uintptr_t>(a.x) & 15) == 0) &&
