@@ -43,4 +43,4 @@ tail -1 $OUT/${TAG}_prof_s1.log | cut -c1-400
 head -12 $OUT/${TAG}_bench_kernel_stats_streams1.csv
 [ -z "$SKIP_PMC" ] && python tools/make_pmc_json.py $OUT/${TAG}_pmc_summary.txt $OUT/${TAG}_pmc_summary_bf16x3.txt > $OUT/${TAG}_pmc_dominant_kernel.json
 # keep the merged-back payload small
-rm -rf $OUT/${TAG}_prof_s1 $OUT/${TAG}_prof_s2 $OUT/${TAG}_prof_b3 $OUT/${TAG}_pmc_1* $OUT/${TAG}_pmc_w_*
+rm -rf $OUT/${TAG}_prof_s1 $OUT/${TAG}_prof_s2 $OUT/${TAG}_prof_b3 $OUT/${TAG}_pmc_[0-9]* $OUT/${TAG}_pmc_w_*
