@@ -43,11 +43,16 @@ __device__ __forceinline__ float& f4c(float4& v, int c) { return c == 0 ? v.x : 
 __device__ __forceinline__ float f4c(const float4& v, int c) { return c == 0 ? v.x : c == 1 ? v.y : c == 2 ? v.z : v.w; }
 
 // Launch-side half of the direct epilogue: `epi` (1 = 16-byte epilogue possible) gains bit 1 when interior tiles may
-// store straight from the accumulators -- no up-sampling, no pooled second output, one residual at most, and every
-// byte offset of y / res1 inside 31 bits (buffer offsets are 32-bit).
-inline int epi_with_direct(const ConvArgs& a, int epi) {
+// store straight from the accumulators -- no up-sampling, no pooled second output, a second residual only at half
+// resolution, and every byte offset of y / res1 / res2 inside 31 bits (buffer offsets are 32-bit).
+inline int epi_with_direct(const ConvArgs& a, int epi, bool half_res_residual = true) {
   const long long M = (long long)a.N * a.OH * a.OW;
-  const bool direct = epi && !a.up2 && a.y_pool == nullptr && a.res2 == nullptr && M * a.ldy * 4 < 0x7fffffffLL &&
+  const int ohw = a.OH * a.OW;
+  // a second residual only in its half-resolution form, on maps where a wave's 32 pixels sit in one frame, start at an
+  // even image row and split into shifts: 2^a x 2^b >= 32 pixels, at least 8 wide
+  const bool r2ok = a.res2 == nullptr || (half_res_residual && a.res2_down && (a.OW & (a.OW - 1)) == 0 && (ohw & (ohw - 1)) == 0 && a.OW >= 8 &&
+                                          ohw >= 32 && (M / 4) * a.ldr2 * 4 < 0x7fffffffLL);
+  const bool direct = epi && !a.up2 && a.y_pool == nullptr && r2ok && M * a.ldy * 4 < 0x7fffffffLL &&
                       (a.res1 == nullptr || M * a.ldr1 * 4 < 0x7fffffffLL);
   return epi | (direct ? 2 : 0);
 }
@@ -149,7 +154,7 @@ struct EpiNoHook {
 // PRE: the caller issued EpiPrefetch::issue() (and the tiling holds a prefetched tile)
 // `staged` runs once the last row block's accumulators sit in the LDS slab (their registers are free from there on):
 // a kernel that finishes its tile in several column slices puts the next slice's residual prefetch there.
-template <int WM, int WN, int TM, int TN, bool UP2, bool PRE, typename HOOK = EpiNoHook>
+template <int WM, int WN, int TM, int TN, bool UP2, bool PRE, typename HOOK = EpiNoHook, bool DIRECT_R2 = true>
 __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x16 (&acc)[TM][TN], float* smem, int m0,
                                               int n0, int M, int epi_vec, const EpiPrefetch<TM, TN>& pre,
                                               HOOK staged = HOOK()) {
@@ -179,6 +184,29 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x16 (&acc)[T
         sc[j] = pre.dsc[j];
         sh[j] = pre.dsh[j];
       }
+      // Second residual at HALF resolution (res2_down; the launcher only sets the flag on maps of 2^a x 2^b >= 32 pixels
+      // with OW >= 8): the wave's 32 pixels start at an even image row, so with t = (r & 3) + 8 * (r >> 2) + 4 * lh the
+      // source pixel splits into a wave-uniform part per register r and 2 * lh * ldr2 per lane -- again no vector ALU.
+      // Registers r and r ^ 1 of a lane read the same source pixel: 8 loads per column tile.
+      float r2[DIRECT_R2 ? TN : 1][8];
+      if (DIRECT_R2 && p.res2 != nullptr) {                                   // (uniform) direct tiles carry res2 only as res2_down
+        const auto rs_2 = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<float*>(p.res2), 0, (int)(((unsigned)((M >> 2) - 1) * p.ldr2 + (unsigned)p.Cout) * 4u), 0x00020000);
+        const int ohw = p.OH * p.OW, ow_sh = __ffs(p.OW) - 1;
+        const int mb = __builtin_amdgcn_readfirstlane(m0 + wm * 32);
+        const int fr = mb >> (__ffs(ohw) - 1), pos = mb & (ohw - 1);
+        const int oh0 = pos >> ow_sh, ow0 = pos & (p.OW - 1);
+        const int v2 = (2 * lh * p.ldr2 + ncol) * 4;
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+          for (int h = 0; h < 8; ++h) {
+            const int tr = 2 * (h & 1) + 8 * (h >> 1);              // rows (2h, 2h + 1) -> registers r = 2h, 2h + 1
+            const int oh = oh0 + (tr >> ow_sh), ow = ow0 + (tr & (p.OW - 1));
+            const int src = (fr * (p.OH >> 1) + (oh >> 1)) * (p.OW >> 1) + (ow >> 1);
+            r2[j][h] = buf_ld1_stream(rs_2, v2, (src * p.ldr2 + j * 32) * 4);
+          }
+      }
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -188,6 +216,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x16 (&acc)[T
             float t = acc[i][j][r];
             if (p.post_scale != nullptr) t = t * sc[j] + sh[j];
             if (p.res1 != nullptr) t += f4c(pre.r1[i][j * 4 + (r >> 2)], r & 3);
+            if (DIRECT_R2 && p.res2 != nullptr) t += r2[DIRECT_R2 ? j : 0][r >> 1];
             if (p.post_relu) t = fmaxf(t, 0.f);
             buf_st1_stream(rs_y, vo, ((i * 32 + (r & 3) + 8 * (r >> 2)) * p.ldy + j * 32) * 4, t);
           }

@@ -232,7 +232,7 @@ __global__ __launch_bounds__(256, 2) void conv_halo_kernel(const ConvArgs p, con
     __syncthreads();
   }
 
-  conv_epilogue<4, 1, 1, TN, false, true>(p, acc, smem, m0, n0, M, epi_vec, pre);
+  conv_epilogue<4, 1, 1, TN, false, true, EpiNoHook, false>(p, acc, smem, m0, n0, M, epi_vec, pre);
 }
 
 bool geometry(const ConvArgs& a, int tn, HaloGeom* g) {

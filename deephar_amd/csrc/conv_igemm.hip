@@ -327,7 +327,7 @@ int launch_conv_igemm(const ConvArgs& a, int cfg, hipStream_t s) {
                   (a.res2 == nullptr || (a.ldr2 % 4 == 0 && al16(a.res2))) &&
                   (a.post_scale == nullptr || (al16(a.post_scale) && al16(a.post_shift)));
   if (a.y_pool != nullptr && !epi) return DH_EUNSUPPORTED;
-  if (a.w_split == 2) return launch_conv_halo(a, cfg, epi_with_direct(a, epi), s);   // chunk-major fp32 packing: the halo-resident kernel only
+  if (a.w_split == 2) return launch_conv_halo(a, cfg, epi_with_direct(a, epi, false), s);   // chunk-major fp32 packing: the halo-resident kernel only
   if (cfg < 0 && a.y_pool != nullptr) {
     cfg = conv_igemm_pick_cfg(a.N * a.OH * a.OW, a.Cout);
     if (cfg == 8) cfg = 7;                // 32 x 32 has no wave pair
