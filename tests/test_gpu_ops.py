@@ -417,7 +417,11 @@ def test_kxk_conv_on_the_dma_kernel(case, cfg, hip_lib, cuda):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize('case', [(2, 32, 32, 576, 576, False), (3, 16, 16, 288, 288, False), (2, 32, 32, 64, 100, True),
-                                  (1, 8, 8, 48, 40, False)])
+                                  (1, 8, 8, 48, 40, False),
+                                  # the direct epilogue's index split: rows wider than a wave's 32 pixels, a wide low map,
+                                  # and maps that are not 2^a x 2^b (those stay on the staged epilogue)
+                                  (1, 64, 64, 32, 64, False), (2, 8, 128, 32, 96, True), (1, 12, 24, 32, 64, False),
+                                  (2, 4, 8, 64, 32, False)])
 def test_conv2d_second_residual_at_half_resolution(case, hip_lib, cuda):
     """dh_conv_args.res2_down: out = BN(conv(x)) + res1 + UpSampling2D(res2) with res2 at half resolution -- the
     hourglass' add([a, UpSampling2D(b)]) (reception.py:122-127) folded into the convolution that produces a.  Equal, bit
