@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """Headline benchmark of the pose-regression hot path on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W [--workload mpii|penn_merge|ntu_spnet]
+    python bench.py --gpus N --steps K --warmup W [--workload mpii|h36m|penn_merge|ntu_spnet]
         (N > 1 without torch.distributed.run around it: bench.py starts the N ranks itself)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 
@@ -9,6 +9,8 @@ Workloads (BASELINE.json `configs`):
   mpii        (default; configs[1], the configuration `metric` is quoted on) ReceptionNet 8 blocks, J=16, 2 contexts,
               5x5: one step = one forward over a batch of 64 synthetic 256x256x3 frames per GPU.  Frames shard over
               ranks with no data-path collective (weak scaling).
+  h36m        (configs[2]) ReceptionNet dim=3, 8 blocks, J=17, 16 depth maps (exp/h36m/eval_h36m.py:42-48): batch 128
+              per GPU, frames shard like mpii.
   penn_merge  (configs[3]) merge model, 16-frame clips, 4 blocks, 15 actions, 4 clips per GPU and step;
   ntu_spnet   (configs[4]) SPNet pa17j3d, 60 actions, 32-frame clips, 8 clips per GPU and step.
               Clip workloads are FRAME-SHARDED: every rank runs T/N frames of all N x clips_per_gpu clips through the
@@ -66,6 +68,16 @@ def build_mpii(blocks=8):
     return m
 
 
+def build_h36m():
+    """exp/h36m/eval_h36m.py:42-48: 3-D pose, 8 blocks, 17 joints, 16 depth maps per joint, 5x5 kernels."""
+    from deephar_amd import graph, weights
+    from deephar_amd.models import reception
+    graph.reset_naming()
+    m = reception.build((256, 256, 3), 17, dim=3, num_blocks=8, depth_maps=16, ksize=(5, 5))
+    weights.init_synthetic(m, seed=0)
+    return m
+
+
 def build_penn_merge():
     """exp/pennaction/eval_penn_ar_pe_merge.py:42-57: 16-frame clips, 4 blocks, J=16, 15 actions."""
     from deephar_amd import graph, weights
@@ -95,6 +107,9 @@ WORKLOADS = {
     'mpii': dict(build=build_mpii, clips=False, per_gpu=64, T=1,
                  name='MPII single-person 256x256, ReceptionNet 8 blocks J=16 ctx=2 k=5, pose-only forward, batch=64 '
                       'per GPU (BASELINE.json configs[1])'),
+    'h36m': dict(build=build_h36m, clips=False, per_gpu=128, T=1,
+                 name='Human3.6M 3-D pose 256x256, ReceptionNet 8 blocks J=17 dim=3 D=16 k=5, pose-only forward, batch=128 '
+                      'per GPU (BASELINE.json configs[2])'),
     'penn_merge': dict(build=build_penn_merge, clips=True, per_gpu=4, T=16,
                        name='PennAction pose+action merge model, 16-frame 256x256 clips, 4 blocks, 4 clips per GPU, '
                             'frame-shard + RCCL all-gather (BASELINE.json configs[3])'),
@@ -116,35 +131,61 @@ def cpu_model_string():
     return 'unknown'
 
 
-def cpu_baseline(model, blocks):
-    """Oracle (torch-CPU fp32) frames/s: batch 16, median of 5 after one warm-up."""
+def cpu_baseline(model, workload, blocks):
+    """The CPU oracle (PyTorch-CPU fp32; a port -- TensorFlow/Keras are not installable here) on this box's host cores, on
+    a BOUNDED sample of the same workload: a batch of 16 frames (mpii, h36m) or one clip (penn_merge: 16 frames,
+    ntu_spnet: 32 frames); median of up to 5 runs after one warm-up, at most ~25 s."""
     import torch
     from deephar_amd import weights
-    from oracle import reception as oref
     from oracle.naming import Weights
     # all cores up to 32: beyond that PyTorch-CPU's conv threading on a many-socket host gets slower, not
     # faster (measured: 256 threads -> 0.05 frames/s on the GPU box)
     cores = min(os.cpu_count() or 1, 32)
     torch.set_num_threads(cores)
-    wd = Weights(weights.as_dict(model))
-    bs = 16
-    x = np.random.default_rng(0).uniform(-1, 1, (bs, 256, 256, 3)).astype(np.float32)
-    kw = dict(num_context_per_joint=2, num_blocks=blocks, ksize=(5, 5), concat_pose_confidence=False)
-    oref.forward(wd, x, 16, 2, **kw)  # warm-up
+    rng = np.random.default_rng(0)
+    if workload in ('mpii', 'h36m'):
+        from oracle import reception as oref
+        wd = Weights(weights.as_dict(model))
+        frames = 16
+        x = rng.uniform(-1, 1, (frames, 256, 256, 3)).astype(np.float32)
+        if workload == 'mpii':
+            kw = dict(num_context_per_joint=2, num_blocks=blocks, ksize=(5, 5), concat_pose_confidence=False)
+            run = lambda: oref.forward(wd, x, 16, 2, **kw)
+        else:
+            run = lambda: oref.forward(wd, x, 17, 3, num_blocks=8, depth_maps=16, ksize=(5, 5))
+        what, src = 'a batch of %d frames' % frames, 'oracle/reception.py'
+    elif workload == 'penn_merge':
+        from oracle import action as oact
+        wd = weights.as_dict(model)
+        frames = 16
+        x = rng.uniform(-1, 1, (1, 16, 256, 256, 3)).astype(np.float32)
+        run = lambda: oact.forward_merge(wd, x, 15, 16, 4, pose_dim=2, pose_net_version='v1', output_poses=True)
+        what, src = 'one 16-frame clip', 'oracle/action.py'
+    else:
+        from oracle import spnet as osp
+        wd = weights.as_dict(model)
+        frames = 32
+        x = rng.uniform(-1, 1, (1, 32, 256, 256, 3)).astype(np.float32)
+        ocfg = dict(num_joints=17, dim=3, num_actions=[60], num_pyramids=2, action_pyramids=[1, 2], num_levels=4,
+                    kernel_size=(5, 5), growth=96, image_div=8, num_pose_features=192, num_visual_features=192,
+                    sam_alpha=1, pose_replica=False)
+        run = lambda: osp.forward(wd, x, ocfg)
+        what, src = 'one 32-frame clip', 'oracle/spnet.py'
+    run()  # warm-up
     ts = []
     t_all = time.perf_counter()
     for _ in range(5):
         t0 = time.perf_counter()
-        oref.forward(wd, x, 16, 2, **kw)
+        run()
         ts.append(time.perf_counter() - t0)
         if time.perf_counter() - t_all > 25.0:      # bounded sample on a slow host
             break
     med = float(np.median(ts))
-    return dict(value=round(bs / med, 2), unit='frames/s', cores=cores, kind='port', cpu=cpu_model_string(),
+    return dict(value=round(frames / med, 2), unit='frames/s', cores=cores, kind='port', cpu=cpu_model_string(),
                 host_logical_cpus=os.cpu_count(),
                 sample='CPU-oracle baseline (stand-in for the reference TF-CPU path; TF/Keras absent from the image): '
-                       'batch of %d frames of the same 256x256x3 workload through oracle/reception.py (PyTorch-CPU '
-                       'fp32, %d threads), median of %d runs after 1 warm-up, %.2f s per batch' % (bs, cores, len(ts), med))
+                       '%s of the same 256x256x3 workload through %s (PyTorch-CPU fp32, %d threads), median of %d runs '
+                       'after 1 warm-up, %.2f s per run' % (what, src, cores, len(ts), med))
 
 
 # ---- kernel naming / roofline -----------------------------------------------------------------------------------------
@@ -173,6 +214,28 @@ def kernel_name(s):
     return 'conv_igemm_kernel<%d, %d, %d, %d, %s, %s>' % (t + (b(vec4), b(a['up2'])))
 
 
+def epilogue_tag(s):
+    """What a conv launch does after the accumulation, as a short tag: part of the identity of a measured launch
+    (a second residual is 37 MB more algorithmic traffic on the dominant shape)."""
+    a = s.attrs
+    parts = []
+    if a.get('pre_relu'):
+        parts.append('prerelu')
+    if 'post_bn' in s.params:
+        parts.append('bn')
+    if s.ins.get('res1') is not None:
+        parts.append('res1')
+    if s.ins.get('res2') is not None:
+        parts.append('res2down' if a.get('res2_down') else 'res2')
+    if a.get('post_relu'):
+        parts.append('relu')
+    if a.get('up2'):
+        parts.append('up2')
+    if s.outs.get('ypool') is not None:
+        parts.append('pool')
+    return '+'.join(parts) or 'plain'
+
+
 def profile_plans(bound):
     """bound: [(BoundPlan, stream_ptr)].  Per-step HIP-event times of an eager pass -> (rows, kinds)."""
     rows, kinds = [], {}
@@ -196,7 +259,7 @@ def roofline(rows, kinds, total_flops_per_step, ms_per_step):
                 launches=sum(kinds[k]['launches'] for k in conv_kinds))
     eager_total_ms = sum(ms for _, ms, _ in rows)
     by_kernel = {}
-    for s, ms, n in rows:
+    for idx, (s, ms, n) in enumerate(rows):
         if s.kind != 'conv':
             continue
         g = by_kernel.setdefault(kernel_name(s), dict(ms=0.0, flops=0.0, launches=0, shapes={}))
@@ -204,29 +267,38 @@ def roofline(rows, kinds, total_flops_per_step, ms_per_step):
         g['flops'] += s.flops(n)
         g['launches'] += 1
         x, y = s.ins['x'], s.outs['y']
-        key = (n * x.lead(3) * y.shape[-3] * y.shape[-2] // (4 if s.attrs['up2'] else 1), s.attrs['K'], s.attrs['Cout'])
-        sh = g['shapes'].setdefault(key, dict(ms=0.0, launches=0, flops=s.flops(n), bytes=s.bytes(n)))
+        key = (n * x.lead(3) * y.shape[-3] * y.shape[-2] // (4 if s.attrs['up2'] else 1), s.attrs['K'], s.attrs['Cout'],
+               epilogue_tag(s))
+        sh = g['shapes'].setdefault(key, dict(ms=0.0, launches=0, flops=s.flops(n), bytes=s.bytes(n), step=idx))
         sh['ms'] += ms
         sh['launches'] += 1
     dom_name, dom = max(by_kernel.items(), key=lambda kv: kv[1]['ms'])
     achieved = dom['flops'] / (dom['ms'] * 1e-3) / 1e12
     # the shape this instantiation spends most of its time on: its algorithmic bytes (operands read once, result
     # written once: Step.bytes) and, when the PMC passes of the same instantiation + shape exist, its HBM traffic
-    (m_, k_, n_), main = max(dom['shapes'].items(), key=lambda kv: kv[1]['ms'])
-    traffic, traffic_src = None, None
+    (m_, k_, n_, epi_), main = max(dom['shapes'].items(), key=lambda kv: kv[1]['ms'])
+    # `traffic` describes THE SAME launch as `algorithmic_bytes_per_launch`: same instantiation, same M x K x N and the
+    # same epilogue (BN / residuals / half-resolution residual), looked up in the PMC passes of tools/profile_round.py
+    traffic, traffic_src, pmc_extra = None, None, {}
     pmc_path = os.path.join(ROOT, 'profiles', 'pmc_dominant_kernel.json')
     if os.path.exists(pmc_path):
         with open(pmc_path) as f:
             pmc = json.load(f)
-        ent = pmc.get('kernels', {}).get(dom_name)
-        if ent and [m_, k_, n_] == ent.get('shape_mkn'):
-            traffic = ent['fetch_bytes_per_launch'] + ent['write_bytes_per_launch']
-            traffic_src = ent['source']
+        for ent in pmc.get('launches', []):
+            if ent['kernel'] == dom_name and ent['shape_mkn'] == [m_, k_, n_] and ent['epilogue'] == epi_ and \
+                    abs(ent['algorithmic_bytes_per_launch'] - main['bytes']) <= 1e-6 * main['bytes']:
+                traffic = ent['fetch_bytes_per_launch'] + ent['write_bytes_per_launch']
+                traffic_src = ent['source']
+                pmc_extra = {'traffic_over_algorithmic': round(traffic / main['bytes'], 4)}
+                if 'mfma_busy_fraction' in ent:
+                    pmc_extra['pmc_mfma_busy_fraction'] = ent['mfma_busy_fraction']
+                break
     out = {'bound': 'mfma', 'kernel': dom_name,
            'achieved': round(achieved, 2), 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
            'frac': round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), 'traffic': traffic,
            'traffic_unit': 'bytes/launch (HBM read + write, PMC) of the main shape', 'traffic_source': traffic_src,
-           'main_shape_mkn': [m_, k_, n_], 'main_shape_launches_per_step': main['launches'],
+           'main_shape_mkn': [m_, k_, n_], 'main_shape_epilogue': epi_, 'main_shape_step_index': main['step'],
+           'main_shape_launches_per_step': main['launches'],
            'main_shape_avg_launch_us': round(1e3 * main['ms'] / main['launches'], 2),
            'algorithmic_bytes_per_launch': main['bytes'], 'algorithmic_gflop_per_launch': round(main['flops'] / 1e9, 3),
            'launches_per_step': dom['launches'],
@@ -238,6 +310,7 @@ def roofline(rows, kinds, total_flops_per_step, ms_per_step):
                                      'frac': round(conv['flops'] / (conv['ms'] * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4),
                                      'gflop_per_step': round(conv['flops'] / 1e9, 2)},
            'whole_forward_frac': round(total_flops_per_step / (ms_per_step * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4)}
+    out.update(pmc_extra)
     extra = {'kernel_time_share': {k: round(v['ms'] / eager_total_ms, 4) for k, v in sorted(kinds.items())},
              'hbm_bound_kernels': {k: {'GBps': round(v['bytes'] / (v['ms'] * 1e-3) / 1e9, 1),
                                        'frac_of_8TBps': round(v['bytes'] / (v['ms'] * 1e-3) / 1e9 / PEAK_HBM_GBS, 4)}
@@ -422,6 +495,11 @@ def main():
                          'keeps rocprofv3 kernel stats clean), written otherwise')
     ap.add_argument('--dry-run', action='store_true',
                     help='launcher / rendezvous / all-gather / JSON contract on the gloo backend, no HIP device')
+    ap.add_argument('--replay-step', type=int, default=None,
+                    help='profiling aid (tools/profile_round.py): bind the workload, run ONE forward, then launch step '
+                         'number I of the bound plan(s) --replay-reps times with its in-model arguments and exit; the '
+                         'PMC passes of rocprofv3 read the last launches of that kernel')
+    ap.add_argument('--replay-reps', type=int, default=4)
     ap.add_argument('--predict-frames', type=int, default=2048,
                     help='frames per Model.predict boundary measurement (SURVEY.md 8d: >= 2 000)')
     args = ap.parse_args()
@@ -455,6 +533,8 @@ def main():
     wl = WORKLOADS[args.workload]
     per_gpu = args.batch or wl['per_gpu']
     model = wl['build'](args.blocks) if args.workload == 'mpii' else wl['build']()
+    if args.workload == 'h36m':
+        args.no_bf16x3 = args.no_clip_leg = True
     if args.streams is not None:
         model.num_streams = args.streams
     if args.gemm is not None:
@@ -517,6 +597,21 @@ def main():
     else:
         (step, pairs, bound, streams, frames_per_step, flops_per_step, check, parallelism, restage) = \
             setup_clips(args.workload, model, per_gpu, world, rank, args, load_tune, save_tune)
+
+    if args.replay_step is not None:
+        step()
+        for s_ in streams:
+            s_.synchronize()
+        calls = [(bp, sp, c) for bp, sp in bound for c in bp.calls]
+        bp, sp, (fn, cargs, st) = calls[args.replay_step]
+        for _ in range(args.replay_reps):
+            rc = fn(*cargs, sp)
+            assert rc == 0, rc
+        torch.cuda.synchronize()
+        print(json.dumps({'replayed_step': args.replay_step, 'kind': st.kind, 'name': st.name,
+                          'kernel': kernel_name(st) if st.kind == 'conv' else st.kind, 'reps': args.replay_reps,
+                          'algorithmic_bytes': st.bytes(bp.n), 'gflop': st.flops(bp.n) / 1e9}))
+        return
 
     dt = timed(step, streams, args.steps, args.warmup, world, pairs)
     if wl['clips']:
@@ -588,6 +683,7 @@ def main():
     if rank == 0:
         out = {
             'metric': 'frames/sec whole-node, 256x256 MPII pose fwd' if args.workload == 'mpii' else
+                      'frames/sec whole-node, 256x256 Human3.6M 3-D pose fwd' if args.workload == 'h36m' else
                       'frames/sec whole-node, 256x256 pose + action fwd (%s)' % args.workload,
             'value': round(frames_per_step * args.steps / dt, 1),
             'unit': 'frames/s',
@@ -622,8 +718,8 @@ def main():
             out['predict_note'] = 'Model.predict on host numpy arrays, %d frames in batches of %d, wall clock incl. ' \
                                   'H2D of the frames and D2H of all outputs, after one warm-up call' % (
                                       args.predict_frames, per_gpu)
-        if world == 1 and not args.no_cpu_baseline and args.workload == 'mpii':
-            out['cpu_baseline'] = cpu_baseline(model, args.blocks)
+        if world == 1 and not args.no_cpu_baseline:
+            out['cpu_baseline'] = cpu_baseline(model, args.workload, args.blocks)
         if args.dump_steps:
             dump = [dict(kind=s.kind, name=s.name, kernel=kernel_name(s) if s.kind == 'conv' else s.kind,
                          ms=ms, gflop=s.flops(n) / 1e9, mbytes=s.bytes(n) / 1e6,

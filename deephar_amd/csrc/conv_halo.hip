@@ -274,11 +274,9 @@ int launch_tn(const ConvArgs& a, int epi, const HaloGeom& g, hipStream_t s) {
   if (lds < epi_bytes) lds = epi_bytes;
   auto kern = a.pre_relu ? conv_halo_kernel<KW, TN, true> : conv_halo_kernel<KW, TN, false>;
   if (lds > 64 * 1024) {
-    static bool once_t = (hipFuncSetAttribute((const void*)conv_halo_kernel<KW, TN, true>,
-                                              hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024), true);
-    static bool once_f = (hipFuncSetAttribute((const void*)conv_halo_kernel<KW, TN, false>,
-                                              hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024), true);
-    (void)once_t; (void)once_f;
+    static LdsLimit lim_t, lim_f;
+    lim_t.raise((const void*)conv_halo_kernel<KW, TN, true>, 80 * 1024);
+    lim_f.raise((const void*)conv_halo_kernel<KW, TN, false>, 80 * 1024);
   }
   hipLaunchKernelGGL(kern, dim3((unsigned)tiles), dim3(256), (size_t)lds, s, a, epi, g);
   return check_launch();

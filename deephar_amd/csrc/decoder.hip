@@ -600,9 +600,8 @@ int launch_softargmax2d(const SamArgs& a, hipStream_t s) {
   const long long blocks4 = (long long)a.F * ((a.C + 3) / 4);
   if (blocks4 > 0x7fffffffLL) return DH_EINVAL;
   constexpr size_t kMaxSlab = 128 * 1024;     // 32x32x16 maps need 64 KB: above the default dynamic-LDS limit
-  static bool once = (hipFuncSetAttribute((const void*)softargmax2d_kernel<16, true>,
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxSlab), true);
-  (void)once;
+  static LdsLimit lim;
+  lim.raise((const void*)softargmax2d_kernel<16, true>, (int)kMaxSlab);
   const bool wide = blocks16 >= 1024;
   const int g = wide ? 16 : 4;
   const size_t slab = ((size_t)a.H * a.W * g + a.W + a.H) * sizeof(float);
@@ -628,9 +627,8 @@ int launch_softargmax2d_context(const SamArgs& a, int J, int nctx, float agg_alp
   if (slab > 128 * 1024) return DH_EUNSUPPORTED;
   // 16 channel lanes x 64 pixel lanes: sixteen pixels per thread and pass, like the four-channel soft-argmax variant
   constexpr int NT = 1024;
-  static bool once = (hipFuncSetAttribute((const void*)softargmax2d_ctx_kernel<NT>,
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024), true);
-  (void)once;
+  static LdsLimit lim;
+  lim.raise((const void*)softargmax2d_ctx_kernel<NT>, 128 * 1024);
   hipLaunchKernelGGL(softargmax2d_ctx_kernel<NT>, dim3((unsigned)(a.F * ((J + 3) / 4))), dim3(NT), slab, s, a, J, nctx,
                      agg_alpha, y, ldy);
   return check_launch();

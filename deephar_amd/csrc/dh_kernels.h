@@ -45,6 +45,21 @@ int launch_zeropad(const float* x, float* y, int B, int H, int W, int C, int OH,
 int launch_depth_from_maps(const float* d, int ldd, const float* h, int ldh, float* z, int ldz, int F, int HW,
                            int J, hipStream_t s);
 
+// hipFuncAttributeMaxDynamicSharedMemorySize belongs to the kernel's code object on ONE device: a process that drives
+// several GPUs (Model(device=...), dh_plan executors on other devices) must raise it on each.  One flag word per call
+// site, one bit per device ordinal; a race sets the attribute twice, which is harmless.
+struct LdsLimit {
+  unsigned long long done = 0;
+  void raise(const void* kern, int bytes) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return;
+    const unsigned long long bit = 1ull << (dev & 63);
+    if (done & bit) return;
+    hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    done |= bit;
+  }
+};
+
 inline int check_launch() {
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? DH_OK : DH_ELAUNCH;

@@ -637,9 +637,8 @@ int launch_wide_variant(const ConvArgs& a, int epi, unsigned tiles, hipStream_t 
   constexpr size_t lds = kStage > kEpi ? kStage : kEpi;
   auto kern = gemm1x1s_wide_kernel<WM, UP2, RELU, KXK>;
   if (lds > 64 * 1024) {
-    static bool once = (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                            (int)lds), true);
-    (void)once;
+    static LdsLimit lim;
+    lim.raise((const void*)kern, (int)lds);
   }
   hipLaunchKernelGGL(kern, dim3(tiles), dim3(WM * 64), lds, s, a, epi);
   return check_launch();
@@ -671,9 +670,8 @@ int launch_variant(const ConvArgs& a, int epi, unsigned tiles, hipStream_t s) {
   static_assert(lds <= 160 * 1024, "LDS budget");
   auto kern = gemm1x1s_kernel<WM, WN, TM, TN, UP2, RELU, KXK, NS>;
   if (lds > 64 * 1024) {
-    static bool once = (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                            (int)lds), true);
-    (void)once;
+    static LdsLimit lim;
+    lim.raise((const void*)kern, (int)lds);
   }
   hipLaunchKernelGGL(kern, dim3(tiles), dim3(NT), lds, s, a, epi);
   return check_launch();

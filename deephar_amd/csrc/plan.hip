@@ -180,10 +180,21 @@ int dh_plan_create(const void* blob, size_t blob_bytes, dh_plan** out) {
   if (hipMalloc(&pl->weights, pl->weight_bytes ? pl->weight_bytes : 16) != hipSuccess) return fail(DH_ELAUNCH);
   if (pl->weight_bytes && hipMemcpy(pl->weights, r.p, pl->weight_bytes, hipMemcpyHostToDevice) != hipSuccess)
     return fail(DH_ELAUNCH);
+  // extents, overflow-safe: every factor is bounded by the arena size (in floats) before it is multiplied.  The blob is
+  // trusted, code-equivalent input (it carries launch arguments); these checks catch truncation and mix-ups, they are
+  // not a sandbox.
+  const uint64_t arena_f = pl->arena_bytes / 4, nn = (uint64_t)pl->n;
+  auto fits = [&](uint64_t off_bytes, uint64_t rows, uint64_t pitch, uint64_t last) {   // off + ((rows-1)*pitch + last)*4
+    if (off_bytes % 4 || off_bytes / 4 > arena_f || rows == 0 || pitch > arena_f || last > arena_f || rows > arena_f) return false;
+    const uint64_t room = arena_f - off_bytes / 4;
+    if (pitch != 0 && rows - 1 > room / pitch) return false;
+    return (rows - 1) * pitch + last <= room;
+  };
   for (const In& in : pl->ins)
-    if (in.off + in.items * 4 * pl->n > pl->arena_bytes) return fail(DH_EINVAL);
+    if (in.items == 0 || in.items > arena_f || !fits(in.off, nn, in.items, in.items)) return fail(DH_EINVAL);
   for (const Out& o : pl->outs)
-    if (o.C <= 0 || o.ld < o.C || o.off + ((o.npix * pl->n - 1) * o.ld + o.C) * 4 > pl->arena_bytes) return fail(DH_EINVAL);
+    if (o.C <= 0 || o.ld < o.C || o.npix == 0 || o.npix > arena_f || !fits(o.off, o.npix * nn, (uint64_t)o.ld, (uint64_t)o.C))
+      return fail(DH_EINVAL);
   // patch the pointers (once)
   for (Step& st : pl->steps) {
     const int np = struct_pointers(st.fn);
@@ -275,17 +286,30 @@ int dh_forward(dh_plan* pl, const float* const* inputs, int m, float* const* out
 int dh_forward_host(dh_plan* pl, const float* const* inputs_host, int m, float* const* outputs_host) {
   if (pl == nullptr || inputs_host == nullptr || outputs_host == nullptr || m <= 0 || m > pl->n) return DH_EINVAL;
   if (pl->stream == nullptr) {
-    if (hipStreamCreateWithFlags(&pl->stream, hipStreamNonBlocking) != hipSuccess) return DH_ELAUNCH;
-    for (const In& in : pl->ins) {
+    // staging is built in locals and committed only when every allocation succeeded: a failure part-way leaves the plan
+    // as it was (the next call tries again) instead of with short in_dev / out_dev vectors
+    hipStream_t st = nullptr;
+    std::vector<float*> in_dev, out_dev;
+    bool ok = hipStreamCreateWithFlags(&st, hipStreamNonBlocking) == hipSuccess;
+    for (size_t i = 0; ok && i < pl->ins.size(); ++i) {
       float* q = nullptr;
-      if (hipMalloc(&q, in.items * 4 * (size_t)pl->n) != hipSuccess) return DH_ELAUNCH;
-      pl->in_dev.push_back(q);
+      ok = hipMalloc(&q, pl->ins[i].items * 4 * (size_t)pl->n) == hipSuccess;
+      if (ok) in_dev.push_back(q);
     }
-    for (const Out& o : pl->outs) {
+    for (size_t i = 0; ok && i < pl->outs.size(); ++i) {
       float* q = nullptr;
-      if (hipMalloc(&q, o.npix * o.C * 4 * (size_t)pl->n) != hipSuccess) return DH_ELAUNCH;
-      pl->out_dev.push_back(q);
+      ok = hipMalloc(&q, pl->outs[i].npix * pl->outs[i].C * 4 * (size_t)pl->n) == hipSuccess;
+      if (ok) out_dev.push_back(q);
     }
+    if (!ok) {
+      for (float* q : in_dev) hipFree(q);
+      for (float* q : out_dev) hipFree(q);
+      if (st) hipStreamDestroy(st);
+      return DH_ELAUNCH;
+    }
+    pl->in_dev.swap(in_dev);
+    pl->out_dev.swap(out_dev);
+    pl->stream = st;
   }
   for (size_t i = 0; i < pl->ins.size(); ++i)
     if (hipMemcpyAsync(pl->in_dev[i], inputs_host[i], pl->ins[i].items * 4 * (size_t)m, hipMemcpyHostToDevice,

@@ -445,9 +445,8 @@ template <int KS, int NT, int MAXT, int MAXN, bool AFF, bool RELU>
 int launch_dw_lds_variant(const DwArgs& a, int tw, int rows, unsigned blocks, size_t lds, hipStream_t s) {
   auto kern = dwconv_lds_kernel<KS, NT, MAXT, MAXN, AFF, RELU>;
   if (lds > 64 * 1024) {
-    static bool once = (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds),
-                        true);
-    (void)once;
+    static LdsLimit lim;
+    lim.raise((const void*)kern, (int)lds);
   }
   hipLaunchKernelGGL(kern, dim3(blocks), dim3(NT), lds, s, a, tw, rows, 65536 / (tw + KS - 1) + 1);
   return check_launch();

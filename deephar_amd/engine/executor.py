@@ -454,7 +454,15 @@ class BoundPlan:
             _lib.check(lib.dh_stream_wait_event(stream_ptr, ev), 'join wait')
 
     def capture(self, stream_ptr):
+        """Capture the launch sequence into a hipGraph.  -> False (nothing captured; the caller launches eagerly) when
+        this is a multi-stream plan and the process already holds MAX_MULTISTREAM_GRAPHS such graph execs: they can only
+        be parked, never destroyed (__del__), so their number is what bounds the leak of a long-lived multi-model process."""
+        global _MULTISTREAM_GRAPHS
         lib = self.lib
+        if self.plan.nstreams > 1:
+            if _MULTISTREAM_GRAPHS >= MAX_MULTISTREAM_GRAPHS:
+                return False
+            _MULTISTREAM_GRAPHS += 1
         _lib.check(lib.dh_graph_begin_capture(stream_ptr), 'graph capture begin')
         try:
             self.launch_all(stream_ptr)
@@ -463,6 +471,7 @@ class BoundPlan:
             rc = lib.dh_graph_end_capture(stream_ptr, C.byref(g))
         _lib.check(rc, 'graph capture end')
         self.graph = g
+        return True
 
     def replay(self, stream_ptr):
         _lib.check(self.lib.dh_graph_launch(self.graph, stream_ptr), 'graph launch')
@@ -597,6 +606,10 @@ class BoundPlan:
 
 
 _GRAPH_GRAVEYARD = []
+# multi-stream graph execs ever created by this process (live + parked): capped, see BoundPlan.capture.  One-stream
+# plans (the default, Model.num_streams = 1) destroy their graphs and are not counted.
+_MULTISTREAM_GRAPHS = 0
+MAX_MULTISTREAM_GRAPHS = max(0, int(os.environ.get('DEEPHAR_MAX_MULTISTREAM_GRAPHS', '64')))
 _STAGING_THREADS = max(1, min(8, (os.cpu_count() or 2) // 2, int(os.environ.get('DEEPHAR_STAGING_THREADS', '6'))))
 _POOL = None
 
@@ -712,9 +725,7 @@ class Executor:
 
     def forward(self, bp):
         """Enqueue one forward pass of the bound plan on the executor stream."""
-        if self.use_graph:
-            if bp.graph is None:
-                bp.capture(self.stream_ptr)
+        if self.use_graph and (bp.graph is not None or bp.capture(self.stream_ptr)):
             bp.replay(self.stream_ptr)
         else:
             bp.launch_all(self.stream_ptr)
@@ -823,7 +834,8 @@ class Executor:
                         nsl = max(1, min(_STAGING_THREADS, src.numel() * src.element_size() >> 22, m))
                         step = -(-m // nsl)
                         for a0 in range(0, m, step):
-                            futs.append(pool.submit(dst[a0:a0 + step].copy_, src[a0:min(a0 + step, m)]))
+                            a1 = min(a0 + step, m)              # a ragged last chunk: both slices stop at m
+                            futs.append(pool.submit(dst[a0:a1].copy_, src[a0:a1]))
                 return m, on_dev, dev_src, futs
 
             try:

@@ -290,6 +290,8 @@ class Planner:
         but b does not exist yet: it is emitted right after the step that produces b."""
         if not all(self.available(x) for x in node.inputs):
             return False
+        if self._node_is_skinny(node):
+            return False
         t, chain = self._epilogue_tail(node.outputs[0])
         hit = self._upsampled_residual(t) if t is not None else None
         if hit is None or self.available(hit[2]):
@@ -333,8 +335,21 @@ class Planner:
             return v.base, v.bn, v.relu
         return v, None, False
 
-    def _epilogue(self, out_t):
-        """Walk conv -> bn -> relu -> add -> (upsample -> add) while each link has a single consumer."""
+    @staticmethod
+    def _node_is_skinny(node):
+        """True when dh_conv2d_f32 runs this conv / sep-conv node's (pointwise) convolution on the split-K kernel, whose
+        epilogue has no half-resolution residual (conv_igemm.hip: conv_is_skinny + res2_down -> DH_EUNSUPPORTED)."""
+        shape, a = node.outputs[0].shape, node.attrs
+        if len(shape) < 3:
+            return False
+        cin = node.inputs[0].shape[-1]
+        K = cin if node.op == 'sepconv' else a['kh'] * a['kw'] * cin
+        return split_k_rule(shape[-3] * shape[-2], K, a['filters'], cin)
+
+    def _epilogue(self, out_t, skinny=False):
+        """Walk conv -> bn -> relu -> add -> (upsample -> add) while each link has a single consumer.  `skinny`: the
+        convolution runs on the split-K kernel, which cannot read a half-resolution residual (R3 falls back to the
+        up-sampling epilogue / upsample_add)."""
         epi = dict(post_bn=None, post_relu=False, res1=None, res2=None, up2=False, res2_down=False)
         t = out_t
         n = self.sole_consumer(t, 'bn')
@@ -359,7 +374,7 @@ class Planner:
                         epi['res2'] = vals[1]
                     self.absorbed.add(n.uid)
                     t = n.outputs[0]
-            if epi['res2'] is None:
+            if epi['res2'] is None and not skinny:
                 hit = self._upsampled_residual(t)
                 if hit is not None and self.available(hit[2]):
                     a2, up, b = hit
@@ -382,7 +397,9 @@ class Planner:
         return epi, t
 
     def _emit_conv(self, x, pre_bn, pre_relu, param, a, out_t, name):
-        epi, final_t = self._epilogue(out_t)
+        skinny = len(out_t.shape) >= 3 and split_k_rule(out_t.shape[-3] * out_t.shape[-2], a['kh'] * a['kw'] * x.C,
+                                                        a['filters'], x.C)
+        epi, final_t = self._epilogue(out_t, skinny)
         y = self.out_value_for(final_t)
         attrs = dict(kh=a['kh'], kw=a['kw'], sh=a.get('sh', 1), sw=a.get('sw', 1), pt=a['pt'], pl=a['pl'],
                      Cin=x.C, Cout=a['filters'], K=a['kh'] * a['kw'] * x.C, pre_relu=int(pre_relu),
@@ -655,6 +672,15 @@ class Planner:
         if hs.buf is not hc.buf or hs.ld != hc.ld or hc.coff != hs.coff + J or hc.C != J * nctx or J % 4 or hs.ld % 4 or \
                 hs.coff % 4 or hs.shape[:-1] != hc.shape[:-1]:
             return None
+        # the fused step is emitted HERE, after everything planned so far: nothing already emitted may read what the two
+        # read-outs wrote (under another topological order a consumer of the joint confidences could sit in between)
+        first = min(self.plan.steps.index(s_s), self.plan.steps.index(s_c))
+        written = [v for st in (s_s, s_c) for v in st.outs.values() if v is not None]
+        for q in self.plan.steps[first + 1:]:
+            if q is s_s or q is s_c:
+                continue
+            if any(w is not None and any(w.buf is v.buf for v in written) for w in q.ins.values()):
+                return None
         return s_s, s_c, Value(hs.shape[:-1] + (J * (1 + nctx),), hs.buf, hs.coff, hs.ld)
 
     def op_context_agg(self, node):

@@ -83,6 +83,8 @@ def prediction_branch(W, x, num_joints, name, pred_activate=True, forward_maps=T
     x = ops.relu(x)
     if taps is not None and taps.get('want_head_inputs'):
         taps[name + '/in'] = x.numpy().copy()        # what the 1x1 heads read (tests/wellcond.py fits heads on it)
+        if taps.get('stop_at') == name + '/in':      # the fit of this head needs nothing beyond this point
+            raise StopForward(name)
     pred_maps = _conv(W, x, num_joints, (1, 1), name + '_conv1')
     rep = _conv(W, x, num_joints, (1, 1), name + '_conv1_replica') if replica else None
     if not reinject:
@@ -152,6 +154,11 @@ def action_early_fusion(W, xa, p, c, af, cfg, name, carry=True):
 
 class _State:
     pass
+
+
+class StopForward(Exception):
+    """Raised by forward() when taps['stop_at'] names the head input just recorded (test infrastructure: the head fit
+    of tests/wellcond.py runs one pass per prediction block and reads nothing behind that block)."""
 
 
 def forward(weights, clips, cfg, dtype=torch.float32, taps=None):
@@ -254,6 +261,6 @@ def forward(weights, clips, cfg, dtype=torch.float32, taps=None):
                 final = i == levels[-1]
                 xp, xa = prediction_block(xp, xa, lzp[i], do_action, name + '_pb%d' % i,
                                           last_pose=final and pyr == cfg['num_pyramids'] - 1,
-                                          last_action=final and (pyr + 1) == max(cfg['action_pyramids']))
+                                          last_action=final and (pyr + 1) == max(cfg['action_pyramids'], default=0))
                 lp[i], la[i] = xp, xa
         return [o.numpy() for o in poses + actions]

@@ -3,7 +3,7 @@ on identical seeded weights and inputs, plus size-independent properties at the 
 
 Tolerance (BASELINE.json north_star): joint coordinates within 1e-3 px of a 256-px crop, i.e.
 |d| <= 3.9e-6 in the model's normalised [0,1] output, asserted as max|hip - oracle_fp64| <= 1e-3 px with no
-relative clause (tests/paritylog.py; every comparison also lands in gpurun_out/parity_r03.json together with
+relative clause (tests/paritylog.py; every comparison also lands in gpurun_out/parity_r04.json together with
 |oracle_fp32 - oracle_fp64| and |hip - oracle_fp32|).  SPNet on per-pixel-noise inputs is the one place where the
 synthetic read-out itself is ill-conditioned: those cases are kept here as a stress test under
 paritylog.conditioned_tolerance; SPNet at the flat 1e-3 px bar lives in tests/test_gpu_spnet_flat.py.
@@ -448,6 +448,57 @@ def test_ragged_batches_and_chunking(hip_lib, cuda):
     one = m.predict(x[3:4])
     for a, b in zip(ref, one):
         assert np.array_equal(a[3:4], b)
+
+
+@pytest.mark.parametrize('dtype', ['float32', 'uint8', 'float64'])
+def test_ragged_tail_staged_in_parallel_slices(dtype, hip_lib, cuda):
+    """a last chunk with m < batch_size rows, >= 8 MB of input (so the pinned-staging copy is cut
+    into several row slices) and m % slice != 0 -- 27 frames at batch_size 16 leave m = 11 rows = 8.65 MB of float32,
+    staged as rows [0:6] and [6:11].  The clamped destination slice used to be [6:12] against a source of [6:11]."""
+    import sys, os
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from refgolden import build_case
+    from deephar_amd.engine import executor as ex
+    m, x, _ = build_case('rec2d')
+    rng = np.random.default_rng(5)
+    if dtype == 'uint8':
+        x = rng.integers(0, 256, (27, 256, 256, 3), dtype=np.uint8)
+    else:
+        x = rng.uniform(-1, 1, (27, 256, 256, 3)).astype(dtype)
+    tail = x[16:]
+    nsl = max(1, min(ex._STAGING_THREADS, (tail.size * (1 if dtype == 'uint8' else 4)) >> 22, len(tail)))
+    if dtype != 'uint8':
+        assert nsl >= 2 and len(tail) % -(-len(tail) // nsl) != 0, 'the case no longer exercises a ragged slice'
+    got = m.predict(x, batch_size=16)
+    ref = m.predict(x[16:], batch_size=11)           # the tail on its own, one slice-free chunk of its own size
+    one = m.predict(x[:16], batch_size=16)
+    for g, r, o in zip(got, ref, one):
+        assert g.shape[0] == 27 and np.array_equal(g[16:], r) and np.array_equal(g[:16], o)
+
+
+def test_multi_stream_graphs_are_capped(hip_lib, cuda, monkeypatch):
+    """hipGraphExecs of multi-stream plans can only be parked, never destroyed (ROCm 7.2), so their
+    number per process is capped -- past the cap a multi-stream plan launches eagerly, bit-identically."""
+    import sys, os
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from refgolden import build_case
+    from deephar_amd.engine import executor as ex
+    m, x, _ = build_case('rec2d')
+    x = x.astype(np.float32)
+    ref = m.predict(x, batch_size=2)
+    m.num_streams = 2
+    monkeypatch.setattr(ex, 'MAX_MULTISTREAM_GRAPHS', ex._MULTISTREAM_GRAPHS)       # the cap is reached: no new graph
+    before = ex._MULTISTREAM_GRAPHS
+    got = m.predict(x, batch_size=2)
+    assert ex._MULTISTREAM_GRAPHS == before
+    assert all(bp.graph is None for bp in m.executor.bound.values())
+    for a, b in zip(ref, got):
+        assert np.array_equal(a, b)
+    monkeypatch.setattr(ex, 'MAX_MULTISTREAM_GRAPHS', before + 1)
+    got = m.predict(x[:1], batch_size=1)                                              # a new bound plan: captures
+    assert ex._MULTISTREAM_GRAPHS == before + 1
+    for a, b in zip(ref, got):
+        assert np.array_equal(a[:1], b)
 
 
 @pytest.mark.parametrize('tag', ['rec2d', 'rec3d', 'merge2d', 'merge3d', 'spnet3d', 'spnet2d', 'spnet2dr'])

@@ -1,5 +1,8 @@
 """SPNet at the FLAT 1e-3 px bar (reference deephar/models/spnet.py:151-248).
 
+Round 4: three input seeds x two clips per configuration, predicted as ONE batch, and a margin
+sweep over the head sensitivity (test_spnet_margin_sweep).
+
 Vectors: tests/wellcond.py -- video clips of low-pass noise and heat-map heads fitted on the oracle so that every
 prediction block has one peak per joint (read-out sensitivity S = sum p |g - x| <= 0.05, asserted from the fp64
 oracle's logits; maps not one-hot).  Checks: plain `paritylog.check(..., PX_TOL)` on x/y (and z) of every prediction
@@ -34,29 +37,34 @@ CONFIGS = {
     'penn_shipped': (8, 'pa16j2d', 15, 6, [5, 6], 160, True),
     'cfg5_ntu_T32': (32, 'pa17j3d', 60, 2, [1, 2], 192, False),
 }
+SEEDS = (0, 1, 2)        # input seeds {0, 1, 2}; the synthetic weights keep their fixed seed
+NCLIPS = 2               # clips per configuration, predicted in ONE batch (configs[4] is 8 clips per GPU: the other six
+                         # are bridged by the bit-exact batch-size invariance of tests/test_gpu_full_configs.py)
 _CACHE = {}
 
 
-def _prepare(name):
+def _prepare(name, seed, nclips=NCLIPS, s_target=None, conditioned=True):
     """Model with fitted heads + clips + fp32 / fp64 oracle outputs; shared by the two GEMM modes of a configuration."""
-    if name in _CACHE:
-        return _CACHE[name]
+    key = (name, seed, nclips, s_target)
+    if key in _CACHE:
+        return _CACHE[key]
     from test_gpu_models import _spnet
     from deephar_amd import weights
     from oracle import spnet as osp
     T, layout, nact, pyr, apyr, feats, replica = CONFIGS[name]
-    seed = 40 + sorted(CONFIGS).index(name)
-    x = wellcond.video_clips(1, T, 256, seed)
+    vseed = 40 + 10 * seed + sorted(CONFIGS).index(name)      # (seed 0 = the round-3 vectors)
+    x = wellcond.video_cuts(nclips, T, 256, vseed)   # one scene per seed, cut into the clips of the batch
     m, cfg, _, ocfg = _spnet(T, layout, nact, pyr, apyr, feats, replica=replica)
-    wellcond.fit_spnet_heads(m, ocfg, x, wellcond.joint_positions(1, T, ocfg['num_joints'], seed))
+    wellcond.fit_spnet_heads(m, ocfg, x, wellcond.scene_positions(nclips, T, ocfg['num_joints'], vseed),
+                             per_joint=True, **({} if s_target is None else dict(s_target=s_target)))
     wd = weights.as_dict(m)
     t64 = {}
     o32 = osp.forward(wd, x, ocfg, dtype=torch.float32)
     o64 = osp.forward(wd, x, ocfg, dtype=torch.float64, taps=t64)
-    stats = wellcond.assert_well_conditioned(t64, name)
-    _CACHE.clear()                                  # one configuration at a time (a T = 32 clip is 25 MB, fine; models are not)
-    _CACHE[name] = (m, x, ocfg, o32, o64, stats, (pyr, apyr))
-    return _CACHE[name]
+    stats = wellcond.assert_well_conditioned(t64, name) if conditioned else wellcond.conditioning_stats(t64)
+    _CACHE.clear()                                  # one configuration at a time (clips are small; models are not)
+    _CACHE[key] = (m, x, ocfg, o32, o64, stats, (pyr, apyr))
+    return _CACHE[key]
 
 
 def _flat_checks(tag, hip, o32, o64, dim, npose, case):
@@ -72,20 +80,51 @@ def _flat_checks(tag, hip, o32, o64, dim, npose, case):
         assert np.array_equal(hip[k].argmax(-1), o64[k].argmax(-1)), '%s: action label differs on head %d' % (tag, k - npose)
 
 
-@pytest.mark.parametrize('mode', ['f32', 'bf16x3'])
-@pytest.mark.parametrize('name', list(CONFIGS))
-def test_spnet_flat_1e3_px(name, mode, hip_lib, cuda):
+@pytest.mark.parametrize('name,seed,mode', [(n, s, md) for n in CONFIGS for s in SEEDS for md in ('f32', 'bf16x3')])
+def test_spnet_flat_1e3_px(name, seed, mode, hip_lib, cuda):
+    """Three input seeds x two clips per configuration (one batch), both GEMM modes: flat 1e-3 px on every prediction."""
     from deephar_amd.models import spnet
-    m, x, ocfg, o32, o64, stats, (pyr, apyr) = _prepare(name)
+    m, x, ocfg, o32, o64, stats, (pyr, apyr) = _prepare(name, seed)
     m.gemm_precision = mode                          # (an engine option: changing it re-plans the model)
-    hip = m.predict(x, batch_size=1)
+    hip = m.predict(x, batch_size=len(x))
     nsplit = sum(1 for s in m.plan.steps if s.kind == 'conv' and s.attrs.get('w_split') == 1)
     assert (nsplit > 20) == (mode == 'bf16x3'), (mode, nsplit)          # the mode under test is the mode that ran
     npose = spnet.get_num_predictions(pyr, 4)
     assert len(hip) == npose + spnet.get_num_predictions(len(apyr), 4)
     assert [h.shape for h in hip] == [o.shape for o in o64]
-    print('%s: S_max per block %s' % (name, ' '.join('%.3f' % s['S_max'] for s in stats.values())))
-    _flat_checks('%s.%s' % (name, mode), hip, o32, o64, ocfg['dim'], npose, case='spnet_flat/%s/%s' % (name, mode))
+    assert hip[0].shape[0] == NCLIPS
+    print('%s seed %d: S_max per block %s' % (name, seed, ' '.join('%.3f' % s['S_max'] for s in stats.values())))
+    _flat_checks('%s.s%d.%s' % (name, seed, mode), hip, o32, o64, ocfg['dim'], npose,
+                 case='spnet_flat/%s/seed%d/%s' % (name, seed, mode))
+
+
+SWEEP_S = (0.02, 0.04, 0.08, 0.15)
+
+
+@pytest.mark.parametrize('name', ['ntu3d_T8', 'penn2d_T16'])
+def test_spnet_margin_sweep(name, hip_lib, cuda):
+    """How far the engine is from the 1e-3 px bar as the read-out sensitivity S = sum p |g - x| of the fitted heads grows
+    (VERDICT r03 item 1b): the same fit at S_TARGET in {0.02, 0.04, 0.08, 0.15}, one clip, fp32 mode.  RECORDED in
+    gpurun_out/parity_r04.json (`margin_sweep`: S asked / measured, worst |hip - o64|, |o32 - o64|, |hip - o32| over every
+    prediction block); ASSERTED only where S <= wellcond.S_MAX = 0.05, the conditioning the flat test itself requires."""
+    from deephar_amd.models import spnet
+    for s_target in SWEEP_S:
+        m, x, ocfg, o32, o64, stats, (pyr, apyr) = _prepare(name, 0, nclips=1, s_target=s_target, conditioned=False)
+        m.gemm_precision = 'f32'
+        hip = m.predict(x, batch_size=1)
+        npose, dim = spnet.get_num_predictions(pyr, 4), ocfg['dim']
+        s_max = max(s['S_max'] for s in stats.values())
+        flat = lambda a: a.reshape((-1,) + a.shape[-2:])[..., :dim]
+        cat = lambda outs: np.concatenate([flat(o).reshape(-1) for o in outs[:npose]])
+        r = paritylog.record('%s.S%.2f.pose' % (name, s_target), cat(hip), cat(o32), cat(o64),
+                             case='spnet_margin_sweep/%s' % name, S_target=s_target, S_max_measured=s_max,
+                             logit_absmax=max(s['logit_absmax'] for s in stats.values()), tol=1e-3)
+        print('%s S_target %.2f (measured %.3f): hip-o64 %.2e  o32-o64 %.2e  hip-o32 %.2e px' % (
+            name, s_target, s_max, r['hip_vs_o64'], r['o32_vs_o64'], r['hip_vs_o32']))
+        if s_max <= wellcond.S_MAX:
+            assert r['hip_vs_o64'] <= 1e-3, 'S = %.3f: %.3e px' % (s_max, r['hip_vs_o64'])
+        for k in range(npose, len(hip)):
+            assert np.array_equal(hip[k].argmax(-1), o64[k].argmax(-1)), 'action label differs at S = %.2f' % s_target
 
 
 @pytest.mark.parametrize('mode', ['f32', 'bf16x3'])

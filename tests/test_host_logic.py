@@ -148,6 +148,41 @@ def test_planner_fusion_rules():
     assert sum(1 for s in kept.steps if s.kind == 'sam_ctx') == 1
 
 
+def test_planner_r3_spares_split_k_producers():
+    """add([conv(x), UpSampling2D(b)]) must not become the half-resolution second residual (res2_down) of a
+    convolution that dh_conv2d_f32 runs on the split-K kernel (per-frame output <= 256 pixels, K >= 768, Cout <= 256:
+    conv_igemm.hip returns DH_EUNSUPPORTED for that pair) -- the plan falls back to an up-sampling kernel; a producer
+    outside the rule still takes R3."""
+    from deephar_amd import Model, graph
+    from deephar_amd import layers as L
+    from deephar_amd.engine.planner import split_k_rule
+
+    def build(cin, cout, size):
+        graph.reset_naming()
+        inp = L.Input((size, size, cin))
+        low = L.conv2d(L.MaxPooling2D(inp, (2, 2)), cout, (1, 1), name='low')
+        a = L.conv2d(inp, cout, (1, 1), name='a')
+        out = L.add([a, L.UpSampling2D(low, (2, 2))])
+        return Model(inp, [out]).plan
+
+    assert split_k_rule(16 * 16, 1024, 128, 1024)
+    skinny = build(1024, 128, 16)
+    convs = {s.name: s for s in skinny.steps if s.kind == 'conv'}
+    assert not convs['a'].attrs['res2_down'] and 'res2' not in convs['a'].ins
+    assert any(s.kind == 'upsample_add' for s in skinny.steps) or any(s.attrs.get('up2') for s in convs.values())
+    assert not split_k_rule(16 * 16, 512, 128, 512)
+    wide = build(512, 128, 16)
+    convs = {s.name: s for s in wide.steps if s.kind == 'conv'}
+    assert convs['a'].attrs['res2_down'] == 1 and not any(s.kind == 'upsample_add' for s in wide.steps)
+    # sep-conv producer: the rule looks at its pointwise half (K = Cin)
+    graph.reset_naming()
+    inp = L.Input((16, 16, 1024))
+    low = L.conv2d(L.MaxPooling2D(inp, (2, 2)), 128, (1, 1), name='low')
+    a = L.sepconv2d(inp, 128, (3, 3), name='sep')
+    plan = Model(inp, [L.add([a, L.UpSampling2D(low, (2, 2))])]).plan
+    assert not any(s.attrs.get('res2_down') for s in plan.steps if s.kind == 'conv')
+
+
 def test_planner_pooled_output_rule(monkeypatch):
     """R7: the 32-column MaxPooling2D becomes a second output of the convolution that feeds it; same algorithmic FLOPs,
     one launch and one full-resolution read less per block, and the memory plan stays sound (DEEPHAR_FUSE_POOL=0: off)."""

@@ -48,6 +48,25 @@ def video_clips(n_clips, frames, res, seed, sigma=4.0, phase=1.0):
     return out
 
 
+def video_cuts(n_clips, frames, res, seed, sigma=4.0, phase=1.0):
+    """[n_clips, frames, res, res, 3] float32: ONE video of n_clips * frames frames (the rotation of `video_clips`, same
+    total angle `phase`), cut into n_clips consecutive clips -- the clips of a batch show the same scene at different
+    times, so their frames differ while the joints stay where they are (`scene_positions`).  Why not independent scenes
+    per clip: the heads are FITTED, and a 1x1 head over C channels can place J peaks for about as many independent scenes
+    as C / (map cells) allows -- one, at 32 x 32 maps (measured: two independent clips leave the ridge fit of the 32 x 32
+    block at S ~ 0.25 before scaling and the bisection at its cap).  Different seeds are different scenes."""
+    b = lowpass_fields(2, res, seed * 1000, sigma)
+    phi = phase * np.arange(n_clips * frames) / float(n_clips * frames)
+    v = np.cos(phi)[:, None, None, None] * b[0] + np.sin(phi)[:, None, None, None] * b[1]
+    return v.astype(np.float32).reshape(n_clips, frames, res, res, 3)
+
+
+def scene_positions(n_clips, frames, joints, seed):
+    """Target positions for `video_cuts`: one per joint for the whole video, [n_clips * frames, J, 2]."""
+    p = np.random.default_rng(seed + 77).uniform(0.1, 0.9, (1, joints, 2))
+    return np.repeat(p, n_clips * frames, axis=0)
+
+
 def joint_positions(n_clips, frames, joints, seed):
     """One target position per (clip, joint) in normalised [0.1, 0.9]^2, constant over the clip: [n_clips*frames, J, 2]."""
     p = np.random.default_rng(seed + 77).uniform(0.1, 0.9, (n_clips, 1, joints, 2))
@@ -94,11 +113,26 @@ def _scale_for(logits, target):
     return hi
 
 
-def fit_spnet_heads(model, ocfg, clips, pos, s_target=S_TARGET):
+def _scale_per_joint(logits, target):
+    """One factor per joint (output channel of the head), [J]: every joint's maps are brought to max S = target on their
+    own, so that one badly placed peak (a tie between cells keeps S high until the map is nearly one-hot) does not drive
+    the OTHER joints' maps one-hot as the common factor of `_scale_for` does."""
+    j = logits.shape[-1]
+    lo, hi = np.full(j, 0.05), np.full(j, 50.0)
+    for _ in range(30):
+        mid = np.sqrt(lo * hi)
+        over = sensitivity(logits * mid)[0].max(axis=0) > target
+        lo, hi = np.where(over, mid, lo), np.where(over, hi, mid)
+    return hi
+
+
+def fit_spnet_heads(model, ocfg, clips, pos, s_target=S_TARGET, per_joint=False):
     """Fit every '<block>_heatmaps_conv1' of a synthetic SPNet (deephar/models/spnet.py:24-48) so that its maps have
     one peak per joint at `pos`; heads feed the re-injection convs of later blocks, so they are fitted in prediction
     order, one fp32 oracle pass each.  A replica head ('_conv1_replica', spnet.py:36-38) gets 0.9 x the fitted kernel
-    (distinct numbers, same peaks).  Returns {layer name: float32 kernel} of everything it changed."""
+    (distinct numbers, same peaks).  per_joint: the bisection factor is chosen per joint instead of per head (round 4
+    vectors; the committed round-3 goldens were fitted with the common factor).  Returns {layer name: float32 kernel} of
+    everything it changed."""
     import torch
     from deephar_amd import weights
     from oracle import spnet as osp
@@ -108,15 +142,18 @@ def fit_spnet_heads(model, ocfg, clips, pos, s_target=S_TARGET):
     blocks = [k[:-len('/logits')] for k in taps if k.endswith('/logits')]
     changed = {}
     for b in blocks:
-        taps = {'want_head_inputs': True}
-        osp.forward(weights.as_dict(model), clips, ocfg, dtype=torch.float32, taps=taps)
+        taps = {'want_head_inputs': True, 'stop_at': b + '_heatmaps/in'}
+        try:
+            osp.forward(weights.as_dict(model), clips, ocfg, dtype=torch.float32, taps=taps)
+        except osp.StopForward:
+            pass
         f = taps[b + '_heatmaps/in'].astype(np.float64)
         n, h, w, c = f.shape
         x = f.reshape(-1, c)
         y = peak_targets(pos, h, w).reshape(n * h * w, -1)
         g = x.T @ x
         k = np.linalg.solve(g + RIDGE * np.trace(g) / c * np.eye(c), x.T @ y)          # [C, J]
-        k *= _scale_for((x @ k).reshape(n, h, w, -1), s_target)
+        k *= (_scale_per_joint if per_joint else _scale_for)((x @ k).reshape(n, h, w, -1), s_target)
         for name, factor in ((b + '_heatmaps_conv1', 1.0), (b + '_heatmaps_conv1_replica', 0.9)):
             if name in layers:
                 p = layers[name].params[0]
@@ -131,6 +168,17 @@ def apply_heads(model, heads):
         p = layers[name].params[0]
         assert tuple(p.shape) == tuple(k.shape), (name, p.shape, k.shape)
         p.set(np.asarray(k, np.float32))
+
+
+def conditioning_stats(t64):
+    """Per prediction block, from the fp64 oracle's logits: S_max, S_median, min over maps of the top probability,
+    max |logit|.  No assertion (margin sweep)."""
+    stats = {}
+    for key in [k for k in t64 if k.endswith('/logits')]:
+        s, pmax = sensitivity(t64[key])
+        stats[key[:-len('/logits')]] = dict(S_max=float(s.max()), S_median=float(np.median(s)),
+                                            pmax_min=float(pmax.min()), logit_absmax=float(np.abs(t64[key]).max()))
+    return stats
 
 
 def assert_well_conditioned(t64, label=''):
