@@ -194,6 +194,9 @@ def kernel_name(s):
     cfg = s.attrs.get('tile_cfg', -1)
     if s.attrs.get('split_k'):
         return 'conv_splitk_kernel'
+    if s.attrs.get('first_layer'):
+        return 'conv_stem_kernel<%d, %d, %d, %s>' % (s.attrs['kh'], s.attrs['kw'], s.attrs['Cout'] // 32,
+                                                     'true' if s.attrs.get('x_u8') else 'false')
     if cfg < 0:
         return 'conv (library-picked tiling)'
     b = lambda v: 'true' if v else 'false'

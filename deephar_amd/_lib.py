@@ -56,6 +56,7 @@ SIGNATURES = {
     'dh_conv2d_num_split_tile_cfgs': (C.c_int, []),
     'dh_conv2d_pick_tile_cfg': (C.c_int, [C.c_int, C.c_int]),
     'dh_conv2d_uses_split_k': (C.c_int, [C.POINTER(ConvArgs)]),
+    'dh_conv2d_uses_first_layer_kernel': (C.c_int, [C.POINTER(ConvArgs)]),
     'dh_conv2d_split_eligible': (C.c_int, [C.POINTER(ConvArgs)]),
     'dh_conv2d_halo_eligible': (C.c_int, [C.POINTER(ConvArgs)]),
     'dh_conv2d_num_halo_tile_cfgs': (C.c_int, []),

@@ -96,6 +96,9 @@ int dh_conv2d_pack_weights_split_host(const float* w, uint16_t* packed, int KH, 
 int dh_conv2d_num_tile_cfgs(void) { return conv_igemm_num_cfgs(); }
 int dh_conv2d_num_split_tile_cfgs(void) { return gemm1x1_split_num_cfgs(); }
 int dh_conv2d_uses_split_k(const dh_conv_args* a) { return a != nullptr && conv_is_skinny(*a) ? 1 : 0; }
+int dh_conv2d_uses_first_layer_kernel(const dh_conv_args* a) {
+  return a != nullptr && !conv_is_skinny(*a) && conv_stem_eligible(*a) ? 1 : 0;
+}
 int dh_conv2d_pick_tile_cfg(int M, int Cout) { return conv_igemm_pick_cfg(M, Cout); }
 int dh_conv2d_split_eligible(const dh_conv_args* a) { return a != nullptr && gemm1x1_split_eligible(*a) ? 1 : 0; }
 int dh_conv2d_halo_eligible(const dh_conv_args* a) { return a != nullptr && conv_halo_eligible(*a) ? 1 : 0; }

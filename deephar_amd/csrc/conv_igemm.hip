@@ -282,6 +282,8 @@ int gemm1x1_num_cfgs();
 bool conv_is_skinny(const ConvArgs& a);
 int launch_conv_splitk(const ConvArgs& a, hipStream_t s);
 int launch_conv_halo(const ConvArgs& a, int cfg, int epi, hipStream_t s);
+bool conv_stem_eligible(const ConvArgs& a);
+int launch_conv_stem(const ConvArgs& a, hipStream_t s);
 
 // cfg 0..8: general implicit-GEMM kernel; cfg 9..17: the same tile shapes on the LDS-DMA kernel
 int conv_igemm_num_cfgs() { return kNumCfgs + gemm1x1_num_cfgs(); }
@@ -321,6 +323,10 @@ int launch_conv_igemm(const ConvArgs& a, int cfg, hipStream_t s) {
     if (a.res2_down) return DH_EUNSUPPORTED;          // (the split-K kernel has its own, simpler epilogue)
     return cfg < kNumCfgs + gemm1x1_num_cfgs() ? launch_conv_splitk(a, s) : DH_EINVAL;
   }
+  // first layer (3 input channels, stride 2): its own kernel, by a rule on the layer's geometry like the split-K layers --
+  // it pairs the k values of an MFMA differently from the tap-major kernels, so its last bits differ from theirs and a
+  // layer must never move between the two on a timing-based choice
+  if (conv_stem_eligible(a)) return cfg < kNumCfgs + gemm1x1_num_cfgs() ? launch_conv_stem(a, s) : DH_EINVAL;
   auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
   const int epi = (a.Cout % 4 == 0) && (a.ldy % 4 == 0) && al16(a.y) &&
                   (a.res1 == nullptr || (a.ldr1 % 4 == 0 && al16(a.res1))) &&

@@ -18,6 +18,7 @@ int launch_normalize_u8(const unsigned char* x, const float* lut, float* y, long
 int conv_igemm_pick_cfg(int M, int Cout);
 int conv_igemm_num_cfgs();
 bool conv_is_skinny(const ConvArgs& a);
+bool conv_stem_eligible(const ConvArgs& a);
 int gemm1x1_split_num_cfgs();
 bool gemm1x1_split_eligible(const ConvArgs& a);
 bool conv_halo_eligible(const ConvArgs& a);

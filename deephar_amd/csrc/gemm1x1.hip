@@ -10,8 +10,13 @@
 //      with (row & 7).  The DMA destination is lane-linear (wave base + lane*16), so the swizzle lives on the
 //      per-lane SOURCE address and on the fragment read (both-sides-or-neither).
 //   B (weights): host-packed [K/4][N][4] -> the LDS image is the global image, copied linearly.
-//   ReLU-on-load (act_conv_bn) is applied to the A fragments after the ds_read.
+//   ReLU-on-load (act_conv_bn) is applied to the A fragments after the ds_read; so is a BatchNormalization prologue
+//   (PRE: x * scale[k] + shift[k] before the ReLU -- the pre-activation 1x1 convs of SPNet's residual units,
+//   common.py:25-67, whose input has other readers and therefore cannot take the BN in its producer's epilogue): the
+//   per-channel scale / shift sit in LDS behind the two operand stages and are read with the fragments.
 //   Rows >= M and k >= K are clamped to valid addresses: padded weight rows are zero, tail rows never stored.
+#include <algorithm>
+
 #include "conv_common.h"
 
 namespace dh {
@@ -59,6 +64,15 @@ __device__ __forceinline__ float relu1(float v) {
 }
 __device__ __forceinline__ float4 relu4(float4 v) { return make_float4(relu1(v.x), relu1(v.y), relu1(v.z), relu1(v.w)); }
 
+// PRE: scale / shift of the four k values this lane's A fragment of sub-step S covers (k = kt*32 + (2S + lh)*4 + e)
+template <bool PRE, int S>
+__device__ __forceinline__ void fetch_affine(unsigned t_sc, unsigned t_sh, float4& sc, float4& sh) {
+  if constexpr (PRE) {
+    sc = lds_rd<S * 32>(t_sc);
+    sh = lds_rd<S * 32>(t_sh);
+  }
+}
+
 template <int TM, int TN, int BN, int BOFF, int S>
 __device__ __forceinline__ void fetch_frags(const unsigned (&a_addr)[TM][4], unsigned b_addr, float4 (&fa)[TM],
                                             float4 (&fb)[TN]) {
@@ -73,8 +87,9 @@ __device__ __forceinline__ void fetch_frags(const unsigned (&a_addr)[TM][4], uns
 // KXK: the same kernel as an implicit GEMM over a K x K (strided, zero-padded) convolution whose Cin is a multiple
 // of 32: K-step kt covers 32 channels of ONE filter tap, so each staged row is still one contiguous 128-byte run -- of
 // the tap's input pixel, or of a page of zeros when the tap falls into the padding (ReLU-on-load keeps zeros zero).
-template <int WM, int WN, int TM, int TN, bool UP2, bool RELU, bool KXK = false>
+template <int WM, int WN, int TM, int TN, bool UP2, bool RELU, bool KXK = false, bool PRE = false>
 __global__ __launch_bounds__(WM* WN * 64, 2) void gemm1x1_kernel(const ConvArgs p, const int epi_vec) {
+  static_assert(!(PRE && (KXK || UP2)), "the BN prologue is built for the plain pointwise form");
   constexpr int NT = WM * WN * 64;
   constexpr int BM = WM * TM * 32;
   constexpr int BN = WN * TN * 32;
@@ -172,6 +187,13 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void gemm1x1_kernel(const ConvArgs 
 
   const int nk = p.Kp / BK;
   issue(0, 0);
+  if constexpr (PRE) {              // scale | shift tables behind the stages, zero beyond K (k >= K meets zero weights)
+    float* tab = smem + 2 * STAGE;
+    for (int i = tid; i < p.Kp; i += NT) {
+      tab[i] = i < p.K ? p.pre_scale[i] : 0.f;
+      tab[p.Kp + i] = i < p.K ? p.pre_shift[i] : 0.f;
+    }
+  }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
 
@@ -198,12 +220,18 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void gemm1x1_kernel(const ConvArgs 
         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].w, b[j].w, acc[i][j], 0, 0, 0);
       }
   };
-  auto relu_frags = [&](float4 (&a)[TM]) {
+  auto relu_frags = [&](float4 (&a)[TM], const float4& sc, const float4& sh) {
+    if constexpr (PRE) {            // same fused multiply-add as the general kernel's prologue (conv_igemm.hip): same bits
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+        a[i] = make_float4(fmaf(a[i].x, sc.x, sh.x), fmaf(a[i].y, sc.y, sh.y), fmaf(a[i].z, sc.z, sh.z), fmaf(a[i].w, sc.w, sh.w));
+    }
     if constexpr (RELU) {
 #pragma unroll
       for (int i = 0; i < TM; ++i) a[i] = relu4(a[i]);
     }
   };
+  const unsigned t_sc0 = lds0 + (unsigned)(2 * STAGE * 4 + lh * 16);
 
   // NB: an asm ds_read result must be awaited inside the basic block that issued it -- register copies the
   // allocator inserts at block boundaries (loop back-edge, if/else joins) would otherwise copy registers the
@@ -225,26 +253,32 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void gemm1x1_kernel(const ConvArgs 
     // sub-step s+1's fragments are in flight (asm ds_read) while sub-step s's MFMAs run; the first read of the
     // K-step has no MFMAs to hide behind, so the DMA issue of the next tile (address VALU + 6 loads) goes there
     float4 fa0[TM], fb0[TN], fa1[TM], fb1[TN];
+    float4 sc0, sh0, sc1, sh1;                        // PRE only
+    const unsigned t_sc = t_sc0 + (unsigned)(kt * BK * 4), t_sh = t_sc + (unsigned)(p.Kp * 4);
     fetch_frags<TM, TN, BN, BOFF, 0>(a_addr, b_addr, fa0, fb0);
+    fetch_affine<PRE, 0>(t_sc, t_sh, sc0, sh0);
     __builtin_amdgcn_sched_barrier(0);
     if (kt + 1 < nk) issue(kt + 1, cur ^ 1);          // DMA of the next tile flies during this MFMA block
     lgkm_wait();
     fetch_frags<TM, TN, BN, BOFF, 1>(a_addr, b_addr, fa1, fb1);
+    fetch_affine<PRE, 1>(t_sc, t_sh, sc1, sh1);
     __builtin_amdgcn_sched_barrier(0);   // keep the reads ahead of the MFMAs they overlap with
-    relu_frags(fa0);
+    relu_frags(fa0, sc0, sh0);
     mfma_block(fa0, fb0);
     lgkm_wait();
     fetch_frags<TM, TN, BN, BOFF, 2>(a_addr, b_addr, fa0, fb0);
+    fetch_affine<PRE, 2>(t_sc, t_sh, sc0, sh0);
     __builtin_amdgcn_sched_barrier(0);
-    relu_frags(fa1);
+    relu_frags(fa1, sc1, sh1);
     mfma_block(fa1, fb1);
     lgkm_wait();
     fetch_frags<TM, TN, BN, BOFF, 3>(a_addr, b_addr, fa1, fb1);
+    fetch_affine<PRE, 3>(t_sc, t_sh, sc1, sh1);
     __builtin_amdgcn_sched_barrier(0);
-    relu_frags(fa0);
+    relu_frags(fa0, sc0, sh0);
     mfma_block(fa0, fb0);
     lgkm_wait();
-    relu_frags(fa1);
+    relu_frags(fa1, sc1, sh1);
     mfma_block(fa1, fb1);
 
     // tile kt+1 has landed (this wave's DMA) and every wave is done reading tile kt
@@ -255,16 +289,20 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void gemm1x1_kernel(const ConvArgs 
   conv_epilogue<WM, WN, TM, TN, UP2, true>(p, acc, smem, m0, n0, M, epi_vec, pre);
 }
 
-template <int WM, int WN, int TM, int TN, bool UP2, bool RELU, bool KXK = false>
+constexpr int kMaxPreKp = 4096;    // BN prologue: scale + shift tables of at most 2 x 16 KB in LDS
+
+template <int WM, int WN, int TM, int TN, bool UP2, bool RELU, bool KXK = false, bool PRE = false>
 int launch_variant(const ConvArgs& a, int epi, unsigned tiles, hipStream_t s) {
   constexpr int BM = WM * TM * 32, BN = WN * TN * 32, NT = WM * WN * 64;
   constexpr int kStage = 2 * (BM * BK + BK * BN), kEpi = WM * WN * 32 * (TN * 32 + 4);
-  constexpr size_t lds = (size_t)(kStage > kEpi ? kStage : kEpi) * sizeof(float);
-  static_assert(lds <= 160 * 1024, "LDS budget");
-  auto kern = gemm1x1_kernel<WM, WN, TM, TN, UP2, RELU, KXK>;
-  if (lds > 64 * 1024) {
+  constexpr size_t kLds = (size_t)(kStage > kEpi ? kStage : kEpi) * sizeof(float);
+  static_assert(kLds + (PRE ? 2 * kMaxPreKp * sizeof(float) : 0) <= 160 * 1024, "LDS budget");
+  // PRE: the tables sit behind the two stages (the epilogue slab, when larger, only starts after the K loop)
+  const size_t lds = PRE ? std::max(kLds, (size_t)(kStage + 2 * a.Kp) * sizeof(float)) : kLds;
+  auto kern = gemm1x1_kernel<WM, WN, TM, TN, UP2, RELU, KXK, PRE>;
+  if (kLds + (PRE ? 2 * kMaxPreKp * sizeof(float) : 0) > 64 * 1024) {
     static LdsLimit lim;
-    lim.raise((const void*)kern, (int)lds);
+    lim.raise((const void*)kern, (int)(kLds + (PRE ? 2 * kMaxPreKp * sizeof(float) : 0)));
   }
   hipLaunchKernelGGL(kern, dim3(tiles), dim3(NT), lds, s, a, epi);
   return check_launch();
@@ -289,6 +327,9 @@ int launch_cfg(const ConvArgs& a, int epi, hipStream_t s) {
   if (!(a.KH == 1 && a.KW == 1 && a.SH == 1 && a.SW == 1 && a.PT == 0 && a.PL == 0))
     return a.pre_relu ? launch_variant<WM, WN, TM, TN, false, true, true>(a, epi, t, s)
                       : launch_variant<WM, WN, TM, TN, false, false, true>(a, epi, t, s);
+  if (a.pre_scale != nullptr)       // BatchNormalization (+ ReLU) prologue on the A fragments
+    return a.pre_relu ? launch_variant<WM, WN, TM, TN, false, true, false, true>(a, epi, t, s)
+                      : launch_variant<WM, WN, TM, TN, false, false, false, true>(a, epi, t, s);
   return a.pre_relu ? launch_variant<WM, WN, TM, TN, false, true>(a, epi, t, s)
                     : launch_variant<WM, WN, TM, TN, false, false>(a, epi, t, s);
 }
@@ -296,15 +337,18 @@ int launch_cfg(const ConvArgs& a, int epi, hipStream_t s) {
 }  // namespace
 
 bool gemm1x1_eligible(const ConvArgs& a) {
-  const bool aligned = a.pre_scale == nullptr && a.ldx % 4 == 0 && (reinterpret_cast<uintptr_t>(a.x) & 15) == 0 &&
+  const bool aligned = a.ldx % 4 == 0 && (reinterpret_cast<uintptr_t>(a.x) & 15) == 0 &&
                        (reinterpret_cast<uintptr_t>(a.w) & 15) == 0;
   const bool pointwise = a.KH == 1 && a.KW == 1 && a.SH == 1 && a.SW == 1 && a.PT == 0 && a.PL == 0 &&
                          a.H == a.OH && a.W == a.OW && a.Cin % 4 == 0;
   // K x K: a K-step must not straddle filter taps, the up-sampling epilogue is only built for the pointwise form
   const bool kxk = a.Cin % BK == 0 && !a.up2 && a.KH >= 1 && a.KW >= 1 && a.SH >= 1 && a.SW >= 1 && a.PT >= 0 &&
                    a.PL >= 0;
+  // a BatchNormalization prologue: the plain pointwise form only (no zero padding to apply it around, no fused
+  // up-sampling), fp32 weights, tables that fit LDS
+  const bool pre_ok = a.pre_scale == nullptr || (pointwise && !a.up2 && a.w_split == 0 && a.Kp <= kMaxPreKp);
   const bool fits32 = (long long)a.N * a.H * a.W * a.ldx * 4 <= 0xf0000000LL;      // 32-bit buffer offsets
-  return aligned && fits32 && (pointwise || kxk);
+  return aligned && pre_ok && fits32 && (pointwise || kxk);
 }
 
 int launch_gemm1x1(const ConvArgs& a, int cfg, int epi, hipStream_t s) {

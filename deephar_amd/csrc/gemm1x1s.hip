@@ -709,7 +709,7 @@ bool gemm1x1_split_eligible(const ConvArgs& a0) {
   ConvArgs a = a0;
   a.w = reinterpret_cast<const float*>(uintptr_t(16));
   a.w_split = 0;                       // (conv_is_skinny answers for the fp32 packing)
-  if (a.x_u8 || conv_is_skinny(a) || !gemm1x1_eligible(a)) return false;
+  if (a.x_u8 || a.pre_scale != nullptr || conv_is_skinny(a) || !gemm1x1_eligible(a)) return false;   // (no BN prologue on the split path)
   // 32-bit byte offsets into the buffer descriptors
   return (long long)a.N * a.H * a.W * a.ldx * 4 <= 0xf0000000LL && (long long)a.Kp * a.Np * 6 <= 0xf0000000LL;
 }

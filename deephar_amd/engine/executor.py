@@ -250,6 +250,7 @@ class BoundPlan:
             if self.u8 is not None and id(x.buf) in self.u8 and self.u8[id(x.buf)][2]:
                 buf, lut, _ = self.u8[id(x.buf)]
                 args.x, args.in_lut, args.x_u8 = buf.data_ptr(), lut.data_ptr(), 1
+            a['x_u8'] = int(args.x_u8)                 # (read by bench.py to name the kernel)
             split = self.weight_layout(args)           # every field but w / w_split is final here
             wt, kp, np_ = self.store.conv_weight(s.params['w'], split=split)
             assert (kp, np_) == (args.Kp, args.Np)
@@ -511,6 +512,11 @@ class BoundPlan:
             if step.kind == 'conv' and lib.dh_conv2d_uses_split_k(args[0]):
                 step.attrs['tile_cfg'] = -1                      # shape rule: split-K kernel, no tilings to choose from
                 step.attrs['split_k'] = True
+                self.calls[i] = (fn, (args[0], -1), step)
+                continue
+            if step.kind == 'conv' and lib.dh_conv2d_uses_first_layer_kernel(args[0]):
+                step.attrs['tile_cfg'] = -1                      # shape rule: first-layer kernel (conv_stem.hip)
+                step.attrs['first_layer'] = True
                 self.calls[i] = (fn, (args[0], -1), step)
                 continue
             shape_key = ('shape', int(cargs.w_split), self.n, cargs.N * cargs.OH * cargs.OW, cargs.K, cargs.Cout, cargs.KH,

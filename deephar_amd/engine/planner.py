@@ -429,7 +429,9 @@ class Planner:
         pw = dict(kh=1, kw=1, sh=1, sw=1, pt=0, pl=0, filters=a['filters'])
         # depthwise and pointwise stay two launches: a fused kernel (depthwise evaluated as the A operand of the MFMA
         # GEMM) was built in round 2, bit-identical and 7-40 % slower -- nothing issues beside an fp32 MFMA on gfx950
-        # (profiles/r02_sepconv_fusion_study.md; the kernel lives in the history at commit 5d88aa8)
+        # (profiles/r02_sepconv_fusion_study.md; the kernel lives in the history at commit 5d88aa8); a one-launch kernel
+        # for the 8 x 8 level (frame, depthwise result and A operand all resident in LDS) was built in round 4,
+        # bit-identical and neutral: 23-25 us against 11.5 + 15.5 us, step time unchanged (profiles/r04_sepconv8_study.md)
         mid = self.new_value(node.inputs[0].shape)
         params = dict(w=layer.params[0])
         if pre_bn is not None:

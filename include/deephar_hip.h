@@ -68,7 +68,8 @@ typedef struct dh_conv_args {
   int32_t x_u8; /* 1: x points to uint8 frames [N,H,W,ldx]; every byte goes through in_lut before the (optional)
                    BN prologue, zero padding is applied after it.  This is utils/transform.normalize_channels
                    (transform.py:212-231: /255, power, -0.5, *2 in float32) fused into the first convolution; only
-                   the general K x K path takes it (tile_cfg < 0, or one of its tilings 0..8) */
+                   the general K x K path (tile_cfg < 0, or one of its tilings 0..8) and the first-layer kernel
+                   (dh_conv2d_uses_first_layer_kernel) take it */
   int32_t w_split; /* weight layout.  0: fp32, [Kp/4][Np][4], K tap-major.  2: fp32, same container, K chunk-major for the
                       halo-resident K x K kernel (see dh_conv2d_halo_eligible).
                       1: `w` was packed by dh_conv2d_pack_weights_split_host (every weight split exactly into three bf16
@@ -99,7 +100,10 @@ int dh_conv2d_pack_weights_host(const float* w_hwio_host, float* packed_host, in
  * [Kp/8][3 parts][Np][8]; same Kp / Np as dh_conv2d_packed_dims */
 int dh_conv2d_pack_weights_split_host(const float* w_hwio_host, uint16_t* packed_host, int KH, int KW, int Cin,
                                       int Cout);
-/* tile_cfg < 0: library heuristic; 0..dh_conv2d_num_tile_cfgs()-1 forces a tiling (autotuning hook) */
+/* tile_cfg < 0: library heuristic; 0..dh_conv2d_num_tile_cfgs()-1 forces a tiling (autotuning hook): 0..8 the general
+ * implicit-GEMM kernel, 9..17 the same tile shapes on the LDS-DMA GEMM (pointwise, K x K with Cin % 32 == 0; also with a
+ * BatchNormalization prologue when pointwise).  A tiling that does not cover the layer returns DH_EUNSUPPORTED.  All
+ * tilings of a layer give the same bits. */
 int dh_conv2d_num_tile_cfgs(void);
 int dh_conv2d_num_split_tile_cfgs(void); /* tilings of the w_split = 1 kernels: tile_cfg in [0, this) */
 int dh_conv2d_pick_tile_cfg(int M, int Cout);
@@ -108,6 +112,12 @@ int dh_conv2d_pick_tile_cfg(int M, int Cout);
  * Cin only, so that a layer's result bits never depend on tiling choice, batch size or alignment.  Such a layer takes
  * fp32-packed weights (w_split = 0) and ignores tile_cfg. */
 int dh_conv2d_uses_split_k(const dh_conv_args* a);
+/* 1 when dh_conv2d_f32 runs this convolution on the first-layer kernel (conv_stem.hip): 3 dense input channels (ldx = 3,
+ * float or x_u8 frames), stride 2, 3x3 or 7x7, 128 output columns, an even number of output rows, 32 or 64 output
+ * channels, fp32 tap-major weights (w_split = 0), BN / ReLU epilogue only -- layers.conv_bn_act of reception.py:61-66 and
+ * the 7x7 entry conv of spnet.py:317-322 on 256 x 256 frames.  Like the split-K rule it looks at the layer's geometry
+ * only; such a layer ignores tile_cfg. */
+int dh_conv2d_uses_first_layer_kernel(const dh_conv_args* a);
 /* 1 when dh_conv2d_f32 would accept this convolution with w_split = 1 (every field but `w` / `w_split` filled in as for
  * the launch): an LDS-DMA GEMM shape (pointwise, or K x K with Cin % 32 == 0, no fused up-sampling), 16-byte aligned
  * float input, no BN prologue, not a split-K layer, operands within the 32-bit buffer offsets of the kernel.  A

@@ -67,8 +67,7 @@ def test_conv2d_plain(case, hip_lib, cuda):
 
 @pytest.mark.parametrize('cfg', range(18))
 def test_conv2d_every_tile_config(cfg, hip_lib, cuda):
-    """cfg 0..8: general implicit-GEMM kernel (3x3 here); cfg 9..19: the LDS-DMA pointwise kernel (1x1; 18, 19 = its wide
-    32 x 192 per-wave tilings).
+    """cfg 0..8: general implicit-GEMM kernel (3x3 here); cfg 9..17: the same nine tile shapes on the LDS-DMA kernel (1x1).
     All tilings must agree bit-for-bit (same K summation order), which is what lets the autotuner pick freely."""
     from deephar_amd import functional as F
     assert hip_lib.dh_conv2d_num_tile_cfgs() == 18
@@ -100,6 +99,79 @@ def test_pointwise_dma_kernel_matches_general_kernel(cin, cout, hip_lib, cuda):
     torch.cuda.synchronize()
     assert torch.equal(a, b) and torch.equal(a, c)
     _close(a, O.conv2d(O.relu(torch.from_numpy(x)), torch.from_numpy(k)), atol=2e-5, what='pointwise')
+
+
+@pytest.mark.parametrize('cin,cout,relu', [(96, 200, True), (64, 96, True), (100, 36, False), (288, 272, True), (576, 48, False)])
+def test_pointwise_bn_prologue_on_the_dma_kernel(cin, cout, relu, hip_lib, cuda):
+    """Round 4: BatchNormalization (+ ReLU) prologue of a 1x1 convolution on the LDS-DMA GEMM (scale / shift tables in
+    LDS, applied to the A fragments) -- every tiling bit-identical to the general kernel's prologue (same fused
+    multiply-add, same K order), K tails (k >= K: zero table entries against zero weights), Cout and M tails, BN + residual
+    epilogue on top; vs the oracle chain relu?(x * s + b) -> conv."""
+    from deephar_amd import functional as F
+    rng = np.random.default_rng(cin * 7 + cout)
+    x = _rand(rng, (3, 13, 11, cin))
+    k = _rand(rng, (1, 1, cin, cout), np.sqrt(1.0 / cin))
+    ps, pb = rng.uniform(0.5, 1.5, cin).astype(np.float32), _rand(rng, (cin,), 0.5)
+    qs, qb = rng.uniform(0.5, 1.5, cout).astype(np.float32), _rand(rng, (cout,), 0.3)
+    r1 = _rand(rng, (3, 13, 11, cout))
+    d = lambda a: torch.from_numpy(a).to(cuda)
+    t = lambda a: torch.from_numpy(a)
+    pro = t(x) * t(ps) + t(pb)
+    ref = O.conv2d(O.relu(pro) if relu else pro, t(k)) * t(qs) + t(qb) + t(r1)
+    kw = dict(pre_scale=d(ps), pre_shift=d(pb), pre_relu=relu, post_scale=d(qs), post_shift=d(qb), res1=d(r1))
+    base = F.conv2d(d(x), k, tile_cfg=3, **kw)                       # general implicit-GEMM kernel
+    _close(base, ref, atol=3e-5, what='general kernel')
+    for cfg in range(9, 18):
+        got = F.conv2d(d(x), k, tile_cfg=cfg, **kw)
+        torch.cuda.synchronize()
+        assert torch.equal(got, base), 'DMA tiling %d differs from the general kernel' % cfg
+    assert torch.equal(F.conv2d(d(x), k, tile_cfg=-1, **kw), base)
+
+
+@pytest.mark.parametrize('ks,cout,bn', [(3, 32, True), (7, 64, False), (7, 32, True), (3, 64, False)])
+def test_first_layer_kernel(ks, cout, bn, hip_lib, cuda):
+    """Round 4: conv_stem.hip -- 3 input channels, stride 2, TF-SAME asymmetric padding, 256 x 256 frames -> 128 x 128 maps
+    (reception.py:61-66: 3x3 3->32 + BN + ReLU; spnet.py:317-322: 7x7 3->64).  The library takes such a layer by a rule on
+    its geometry (dh_conv2d_uses_first_layer_kernel), whatever tiling is asked for; checked vs the oracle (fp32 and fp64),
+    raw uint8 frames = the loader's float32 values (bitwise), batch-size invariance (bitwise)."""
+    from deephar_amd import functional as F, _lib
+    from deephar_amd.engine.executor import normalization_lut
+    import ctypes as C
+    rng = np.random.default_rng(ks * 100 + cout)
+    n = 3
+    k = _rand(rng, (ks, ks, 3, cout), np.sqrt(1.0 / (ks * ks * 3)))
+    qs, qb = rng.uniform(0.5, 1.5, cout).astype(np.float32), _rand(rng, (cout,), 0.3)
+    d = lambda a: torch.from_numpy(a).to(cuda)
+    kw = dict(post_scale=d(qs), post_shift=d(qb), post_relu=True) if bn else {}
+    xb = rng.integers(0, 256, (n, 256, 256, 3), dtype=np.uint8)
+    lut = normalization_lut(3, 1)
+    x = lut[np.arange(3)[None, None, None, :], xb]                             # the loader's float32 values
+    t = lambda a: torch.from_numpy(a)
+    ref, ref64 = O.conv2d(t(x), t(k), (2, 2), 'same'), O.conv2d(t(x).double(), t(k).double(), (2, 2), 'same')
+    if bn:
+        ref, ref64 = O.relu(ref * t(qs) + t(qb)), O.relu(ref64 * t(qs).double() + t(qb).double())
+    got = F.conv2d(d(x), k, (2, 2), 'same', **kw)
+    got8 = F.conv2d(d(xb), k, (2, 2), 'same', in_lut=d(lut), **kw)
+    forced = F.conv2d(d(x), k, (2, 2), 'same', tile_cfg=4, **kw)                # the rule overrides the tiling
+    one = F.conv2d(d(x[1:2]), k, (2, 2), 'same', **kw)
+    torch.cuda.synchronize()
+    assert got.shape == (n, 128, 128, cout)
+    _close(got, ref, atol=3e-5, what='first layer %dx%d -> %d' % (ks, ks, cout))
+    e_hip = (got.cpu().double() - ref64).abs().max().item()
+    e_cpu = (ref.double() - ref64).abs().max().item()
+    assert e_hip <= 4 * e_cpu + 1e-6, (e_hip, e_cpu)
+    assert torch.equal(got, got8), 'uint8 frames differ from the normalised float frames'
+    assert torch.equal(got, forced) and torch.equal(got[1:2], one)
+    # the rule itself
+    a = _lib.ConvArgs()
+    a.N, a.H, a.W, a.Cin, a.ldx, a.OH, a.OW, a.Cout, a.ldy = n, 256, 256, 3, 3, 128, 128, cout, cout
+    a.KH, a.KW, a.SH, a.SW, a.PT, a.PL, a.K = ks, ks, 2, 2, (ks - 2) // 2, (ks - 2) // 2, ks * ks * 3
+    a.x = a.w = a.y = 16
+    assert hip_lib.dh_conv2d_uses_first_layer_kernel(C.byref(a)) == 1
+    for field, val in (('OW', 64), ('Cin', 4), ('SH', 1), ('Cout', 48), ('w_split', 1), ('pre_relu', 1)):
+        b_ = _lib.ConvArgs.from_buffer_copy(a)
+        setattr(b_, field, val)
+        assert hip_lib.dh_conv2d_uses_first_layer_kernel(C.byref(b_)) == 0, field
 
 
 def test_conv2d_fused_prologue_epilogue(hip_lib, cuda):
@@ -384,7 +456,7 @@ def test_conv2d_uint8_frames_normalised_on_load(k, s, cout, power, hip_lib, cuda
     got = F.conv2d(xb, w, strides=(s, s), in_lut=lut)
     _close(got, want, 2e-5, what='u8 conv vs fp64 oracle')
     with pytest.raises(Exception):
-        F.conv2d(xb, w, strides=(s, s), in_lut=lut, tile_cfg=hip_lib.dh_conv2d_num_tile_cfgs() - 1)   # DMA GEMM: no u8
+        F.conv2d(xb, w, strides=(s, s), in_lut=lut, tile_cfg=17)   # DMA GEMM: no u8
 
 
 @pytest.mark.gpu
