@@ -85,6 +85,74 @@ def test_frame_sharded_clip_model_two_ranks():
     assert [r[3] for r in res] == [(0, 4), (4, 7)]
 
 
+def _host_cost_worker(rank, world, port, q):
+    """Host time of one sharded step with the device work taken out: stages that return a preallocated tensor; timed with
+    the real gloo collective, the collective on its own, and with the collective stubbed -- the last is the Python of
+    ShardedClipModel.forward_device (views of the gathered buffer, channel slices per cut tensor, the re-ordering copies
+    of this CPU stand-in path, output bookkeeping)."""
+    import time
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    torch.set_num_threads(1)
+    try:
+        from deephar_amd import parallel
+        m, _ = _build()
+        runner = parallel.ShardedClipModel(m, frame_fn=None, head_fn=None)
+        n, tl, cp = 4, runner.info['Tl'], runner.info['packed_channels']
+        packed = torch.zeros((n, tl, J, cp))
+        head_out = [torch.zeros((n, NACT)) for _ in runner.info['head_outputs']]
+        runner.frame_fn = lambda x: packed
+        runner.head_fn = lambda parts: head_out
+        x = np.zeros((n, tl, 8, 8, 3), np.float32)
+        steps = 300
+
+        def timed(fn):
+            for _ in range(20):
+                fn()
+            dist.barrier()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                fn()
+            return (time.perf_counter() - t0) / steps * 1e6
+
+        buf = [None]
+
+        def gather_only():
+            buf[0] = parallel.all_gather_rank_major(packed, None, world, out=buf[0])
+        t_step = timed(lambda: runner.forward_device(x))
+        t_coll = timed(gather_only)
+        real = parallel.all_gather_rank_major          # (c) the same step with the collective stubbed out: what is left
+        parallel.all_gather_rank_major = lambda *a, **k: buf[0]
+        try:
+            t_host = timed(lambda: runner.forward_device(x))
+        finally:
+            parallel.all_gather_rank_major = real
+        q.put((rank, t_step, t_coll, t_host))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_host_cost_of_a_sharded_step_two_ranks():
+    """the floor the N > 1 numbers will stand on -- per sharded step the host spends <= 150 us outside
+    the collective (world 2, gloo, merge model's cut: 4 tensors in a 581-channel packed buffer).  On the GPU path the two
+    stages add one hipGraph launch each (~10 us of host time per launch, measured by bench.py's launch loop)."""
+    world, port = 2, _free_port()
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_host_cost_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, t_step, t_coll, t_host in res:
+        print('rank %d: step %.1f us, gloo all-gather alone %.1f us, step without the collective %.1f us' % (
+            rank, t_step, t_coll, t_host))
+        assert t_host <= 150.0, 'rank %d: %.1f us of host time per sharded step outside the collective' % (rank, t_host)
+
+
 def test_split_frames_partitions_merge_and_spnet():
     from deephar_amd import graph, parallel
     from deephar_amd.config import ModelConfig
