@@ -18,6 +18,9 @@ Fusion rules (what the reference leaves to TensorFlow as separate kernels):
                 (reception.py:75,83,87); Lambda channel slices are pointer/ld views (reception.py:171-172).
   R7 pool     : MaxPooling2D((2, 2)) of a 32-column convolution output is a second output of that convolution's epilogue
                 (dh_conv_args.y_pool; reception.py:105-116).
+  R9 wide add : add([...]) with four or more operands is re-associated into one add per convolution that produces an operand
+                (SPNet's re-injection sum, spnet.py:233), a second two-operand add behind a residual add takes the free
+                residual slot (spnet.py:303) -- no element-wise launches are left for either.
   R5 decoder  : channel soft-max + both lin_interpolation_2d + joint confidence (+ global max) on the same
                 maps are one soft-argmax kernel (blocks.py:306-343).
 All tensors are fp32; sizes are tracked per batch item so one plan serves any batch size.
@@ -138,6 +141,8 @@ class Planner:
         self.g_inputs = inputs
         self.g_outputs = outputs
         self.nodes = G.topo_nodes(outputs)
+        if os.environ.get('DEEPHAR_SPLIT_ADDS', '1') != '0':      # (the switch exists for A/B measurements of rule R9)
+            self.nodes = self._split_wide_adds(self.nodes, outputs)
         self.plan = Plan()
         self.val = {}          # tensor uid -> Value | _Lazy
         self.absorbed = set()  # node uids folded into another step
@@ -151,6 +156,62 @@ class Planner:
         self.concat_val = {}   # concat node uid -> Value
         self.processed = set()
         self.deferred = {}     # tensor uid a deferred conv node waits for -> [node]   (R3)
+
+    # ---- R9: n-ary adds are spread over the convolutions that produce their operands ------------------------
+    @staticmethod
+    def _split_wide_adds(nodes, outputs):
+        """add([a, b, c, d, ...]) with four or more operands (SPNet's re-injection sum, spnet.py:233: block input + sep-conv
+        output + one 1x1 convolution per prediction branch) would run as a chain of element-wise launches: a convolution's
+        epilogue takes two residuals.  Re-associate it (on a copy of the node list; the model's graph is untouched) into
+        one add per convolution whose ONLY reader is this sum: the first takes up to two of the other operands, each further
+        one the running partial sum (+ one more operand) -- every partial add is then the epilogue of its convolution (R2)
+        and no element-wise launch is left.  fp32 addition is re-ordered (conv + a + b instead of a + b + conv): within the
+        rounding the 2-residual epilogue of R2 already has."""
+        index = {n.uid: i for i, n in enumerate(nodes)}
+        readers = {}
+        for n in nodes:
+            for t in n.inputs:
+                readers[t.uid] = readers.get(t.uid, 0) + 1
+        for t in outputs:
+            readers[t.uid] = readers.get(t.uid, 0) + 1
+        insert_after, replace = {}, {}
+        for n in nodes:
+            if n.op != 'add' or len(n.inputs) < 4 or len({t.uid for t in n.inputs}) != len(n.inputs):
+                continue
+            prods = [t for t in n.inputs if t.node is not None and t.node.op in ('conv', 'sepconv') and
+                     t.node.uid in index and readers.get(t.uid, 0) == 1]
+            if not prods:
+                continue
+            prods.sort(key=lambda t: index[t.node.uid])
+            others = [t for t in n.inputs if all(t.uid != q.uid for q in prods)]
+            pos = lambda t: index[t.node.uid] if t.node is not None and t.node.uid in index else -1
+            partial, chain = None, []
+            for k, p in enumerate(prods):
+                last = k == len(prods) - 1
+                take = [partial] if partial is not None else []
+                ready = [t for t in others if pos(t) < index[p.node.uid]]
+                while len(take) < 2 and ready:
+                    take.append(ready.pop(0))
+                others = [t for t in others if all(t.uid != q.uid for q in take)]
+                ins = [p] + take + (others if last else [])
+                if not last and len(ins) == 1:            # nothing to add yet: this producer joins the next partial sum
+                    others.append(p)
+                    continue
+                node = G.Node('add', ins, [n.outputs[0].shape], name=(n.name or 'add') + ('' if last else '/part%d' % k))
+                if last:
+                    node.outputs = [n.outputs[0]]          # downstream readers keep their tensor
+                    replace[n.uid] = node
+                else:
+                    insert_after.setdefault(p.node.uid, []).append(node)
+                partial = node.outputs[0]
+                chain.append(node)
+        if not replace:
+            return nodes
+        out = []
+        for n in nodes:
+            out.append(replace.get(n.uid, n))
+            out.extend(insert_after.get(n.uid, []))
+        return out
 
     # ---- helpers ------------------------------------------------------------------------------------
     def new_buf(self, shape, kind='act'):
@@ -382,6 +443,16 @@ class Planner:
                     epi['res2_down'] = True
                     self.absorbed.update((a2.uid, up.uid))
                     t = a2.outputs[0]
+            if epi['res1'] is not None and epi['res2'] is None and os.environ.get('DEEPHAR_SPLIT_ADDS', '1') != '0':
+                # a second two-operand add behind the first (SPNet: add([residual_unit(x), lateral]), spnet.py:303 on top of
+                # common.py:67): the free residual slot takes it -- (conv + shortcut) + lateral, the reference's order
+                n2 = self.sole_consumer(t, 'add')
+                if n2 is not None and len(n2.inputs) == 2:
+                    other = [x for x in n2.inputs if x.uid != t.uid]
+                    if len(other) == 1 and self.available(other[0]):
+                        epi['res2'] = self.materialize(other[0])
+                        self.absorbed.add(n2.uid)
+                        t = n2.outputs[0]
             if epi['res2'] is None:
                 u = self.sole_consumer(t, 'upsample')
                 if u is not None and len(t.shape) >= 3:

@@ -148,6 +148,43 @@ def test_planner_fusion_rules():
     assert sum(1 for s in kept.steps if s.kind == 'sam_ctx') == 1
 
 
+def test_planner_wide_adds_become_conv_epilogues(monkeypatch):
+    """R9: SPNet's four-operand re-injection sum (spnet.py:233) and the lateral add behind a residual unit (spnet.py:303)
+    leave no element-wise launch: every partial sum is the epilogue of a convolution (two residual slots each); the model's
+    own graph is not modified, the memory plan stays sound, FLOPs are conserved (DEEPHAR_SPLIT_ADDS=0: off)."""
+    from deephar_amd import graph, utils
+    from deephar_amd.config import ModelConfig
+    from deephar_amd.models import spnet
+
+    def build():
+        graph.reset_naming()
+        cfg = ModelConfig((4, 128, 128, 3), utils.pa17j3d, num_actions=[60], num_pyramids=2, action_pyramids=[1, 2],
+                          num_levels=4, num_pose_features=64, num_visual_features=64)
+        return spnet.build(cfg)
+    monkeypatch.setenv('DEEPHAR_SPLIT_ADDS', '0')
+    m0 = build()
+    base = m0.plan
+    monkeypatch.setenv('DEEPHAR_SPLIT_ADDS', '1')
+    m1 = build()
+    plan = m1.plan
+    adds = lambda p: [s for s in p.steps if s.kind == 'eltwise' and s.attrs.get('op', 0) == 0 and 'b' in s.ins]
+    assert len(adds(base)) == 15 and len(adds(plan)) == 0 and len(plan.steps) == len(base.steps) - 15
+    assert sum(1 for n in m1._nodes if n.op == 'add' and len(n.inputs) == 4) == 5          # the graph itself keeps its adds (the last block re-injects nothing)
+    assert abs(sum(s.flops() for s in plan.steps) - sum(s.flops() for s in base.steps)) < 1.0
+    assert sum(s.bytes() for s in plan.steps) < sum(s.bytes() for s in base.steps)
+    two = [s for s in plan.steps if s.kind == 'conv' and 'res1' in s.ins and 'res2' in s.ins and not s.attrs.get('res2_down')]
+    assert len(two) >= 9
+    assert [v.shape for v in plan.outputs] == [v.shape for v in base.outputs]
+    for i, s in enumerate(plan.steps):
+        for v in list(s.ins.values()) + list(s.outs.values()):
+            assert v.buf.start <= i <= v.buf.end
+    for i, a in enumerate(plan.bufs):
+        for b in plan.bufs[i + 1:]:
+            live = not (a.end < b.start or b.end < a.start)
+            space = not (a.offset + a.items <= b.offset or b.offset + b.items <= a.offset)
+            assert not (live and space)
+
+
 def test_planner_r3_spares_split_k_producers():
     """add([conv(x), UpSampling2D(b)]) must not become the half-resolution second residual (res2_down) of a
     convolution that dh_conv2d_f32 runs on the split-K kernel (per-frame output <= 256 pixels, K >= 768, Cout <= 256:
