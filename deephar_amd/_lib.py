@@ -82,6 +82,7 @@ SIGNATURES = {
     'dh_plan_num_inputs': (C.c_int, [vp]),
     'dh_plan_num_outputs': (C.c_int, [vp]),
     'dh_plan_input_items': (C.c_int64, [vp, C.c_int]),
+    'dh_plan_input_is_u8': (C.c_int, [vp, C.c_int]),
     'dh_plan_output_items': (C.c_int64, [vp, C.c_int]),
     'dh_forward': (C.c_int, [vp, C.POINTER(vp), C.c_int, C.POINTER(vp), vp]),
     'dh_forward_host': (C.c_int, [vp, C.POINTER(vp), C.c_int, C.POINTER(vp)]),

@@ -12,19 +12,20 @@ namespace {
 
 using dh::check_launch;
 
-enum Fn { F_CONV, F_DW, F_POOL, F_UPADD, F_ELT, F_SAM, F_CTX, F_DMEANS, F_SAM1D, F_KRON, F_GMM, F_COPY, F_ZPAD, F_DFM, F_SAMCTX, F_COUNT };
+enum Fn { F_CONV, F_DW, F_POOL, F_UPADD, F_ELT, F_SAM, F_CTX, F_DMEANS, F_SAM1D, F_KRON, F_GMM, F_COPY, F_ZPAD, F_DFM, F_SAMCTX, F_NORM, F_COUNT };
 
 struct Step { int fn; std::vector<unsigned char> payload; };
-struct In { size_t off, items; };
+struct In { uint64_t tag; size_t items; int u8; char* dst; };   // dst: where dh_forward copies the caller's data (patched)
 struct Out { size_t off, npix; int C, ld; };
 
 }  // namespace
 
 struct dh_plan {
   int n = 0;
-  size_t arena_bytes = 0, weight_bytes = 0;
+  size_t arena_bytes = 0, weight_bytes = 0, byte_bytes = 0;
   char* arena = nullptr;
   char* weights = nullptr;
+  char* bytes = nullptr;        // region 3: uint8 input staging of a uint8-input plan
   std::vector<In> ins;
   std::vector<Out> outs;
   std::vector<Step> steps;
@@ -55,6 +56,7 @@ bool fix(const dh_plan& pl, uint64_t v, void** out) {
   if (v == 0) { *out = nullptr; return true; }
   if (region == 1 && off < pl.arena_bytes) { *out = pl.arena + off; return true; }
   if (region == 2 && off < pl.weight_bytes) { *out = pl.weights + off; return true; }
+  if (region == 3 && off < pl.byte_bytes) { *out = pl.bytes + off; return true; }
   return false;
 }
 
@@ -100,6 +102,7 @@ bool scalar_sig(int fn, int* nargs, unsigned* ptr_mask) {
     case F_COPY: *nargs = 6; *ptr_mask = 0x05; return true;           // x, ldx, y, ldy, npix, C
     case F_ZPAD: *nargs = 10; *ptr_mask = 0x03; return true;          // x, y, B, H, W, C, OH, OW, PT, PL
     case F_DFM: *nargs = 9; *ptr_mask = 0x15; return true;            // d, ldd, h, ldh, z, ldz, F, HW, J
+    case F_NORM: *nargs = 5; *ptr_mask = 0x07; return true;           // x (bytes), lut, y, n_pixels, C
   }
   return false;
 }
@@ -139,6 +142,8 @@ int run_step(const Step& st, void* stream) {
     case F_COPY: return dh_copy_channels_f32(P(0), I(1), P(2), I(3), static_cast<int64_t>(u(4)), I(5), stream);
     case F_ZPAD: return dh_zeropad2d_f32(P(0), P(1), I(2), I(3), I(4), I(5), I(6), I(7), I(8), I(9), stream);
     case F_DFM: return dh_depth_from_maps_f32(P(0), I(1), P(2), I(3), P(4), I(5), I(6), I(7), I(8), stream);
+    case F_NORM: return dh_normalize_u8_f32(reinterpret_cast<const uint8_t*>(P(0)), P(1), P(2), static_cast<int64_t>(u(3)),
+                                            I(4), stream);
   }
   return DH_EINVAL;
 }
@@ -152,15 +157,30 @@ int dh_plan_create(const void* blob, size_t blob_bytes, dh_plan** out) {
   Reader r{static_cast<const unsigned char*>(blob), static_cast<const unsigned char*>(blob) + blob_bytes};
   if (std::memcmp(r.p, "DHPL", 4) != 0) return DH_EINVAL;
   r.p += 4;
-  if (r.get<uint32_t>() != 1) return DH_EINVAL;
+  const uint32_t version = r.get<uint32_t>();
+  if (version != 1 && version != 2) return DH_EINVAL;
   dh_plan* pl = new dh_plan();
   pl->n = r.get<int32_t>();
   pl->arena_bytes = r.get<uint64_t>();
   pl->weight_bytes = r.get<uint64_t>();
   const uint32_t nin = r.get<uint32_t>(), nout = r.get<uint32_t>(), nsteps = r.get<uint32_t>();
+  if (version >= 2) pl->byte_bytes = r.get<uint64_t>();
   auto fail = [&](int rc) { dh_plan_destroy(pl); return rc; };
-  if (!r.ok || pl->n <= 0 || nin == 0 || nout == 0 || nin > 64 || nout > 4096 || nsteps > (1u << 20)) return fail(DH_EINVAL);
-  for (uint32_t i = 0; i < nin; ++i) pl->ins.push_back({(size_t)r.get<uint64_t>(), (size_t)r.get<uint64_t>()});
+  if (!r.ok || pl->n <= 0 || nin == 0 || nout == 0 || nin > 64 || nout > 4096 || nsteps > (1u << 20) ||
+      pl->byte_bytes > (1ull << 40))
+    return fail(DH_EINVAL);
+  for (uint32_t i = 0; i < nin; ++i) {
+    In in{};
+    in.tag = r.get<uint64_t>();
+    in.items = (size_t)r.get<uint64_t>();
+    if (version >= 2) {
+      in.u8 = (int)r.get<uint32_t>();
+      (void)r.get<uint32_t>();
+    } else {
+      in.tag |= 1ull << 60;        // version 1 stored the bare arena offset
+    }
+    pl->ins.push_back(in);
+  }
   for (uint32_t i = 0; i < nout; ++i) {
     Out o;
     o.off = r.get<uint64_t>(); o.npix = r.get<uint64_t>(); o.C = (int)r.get<uint32_t>(); o.ld = (int)r.get<uint32_t>();
@@ -180,6 +200,7 @@ int dh_plan_create(const void* blob, size_t blob_bytes, dh_plan** out) {
   if (hipMalloc(&pl->weights, pl->weight_bytes ? pl->weight_bytes : 16) != hipSuccess) return fail(DH_ELAUNCH);
   if (pl->weight_bytes && hipMemcpy(pl->weights, r.p, pl->weight_bytes, hipMemcpyHostToDevice) != hipSuccess)
     return fail(DH_ELAUNCH);
+  if (pl->byte_bytes && hipMalloc(&pl->bytes, pl->byte_bytes) != hipSuccess) return fail(DH_ELAUNCH);
   // extents, overflow-safe: every factor is bounded by the arena size (in floats) before it is multiplied.  The blob is
   // trusted, code-equivalent input (it carries launch arguments); these checks catch truncation and mix-ups, they are
   // not a sandbox.
@@ -190,8 +211,18 @@ int dh_plan_create(const void* blob, size_t blob_bytes, dh_plan** out) {
     if (pitch != 0 && rows - 1 > room / pitch) return false;
     return (rows - 1) * pitch + last <= room;
   };
-  for (const In& in : pl->ins)
-    if (in.items == 0 || in.items > arena_f || !fits(in.off, nn, in.items, in.items)) return fail(DH_EINVAL);
+  for (In& in : pl->ins) {
+    const uint64_t region = in.tag >> 60, off = in.tag & ((1ull << 60) - 1);
+    if (in.u8 == 0) {
+      if (region != 1 || in.items == 0 || in.items > arena_f || !fits(off, nn, in.items, in.items)) return fail(DH_EINVAL);
+      in.dst = pl->arena + off;
+    } else {                       // uint8 frames land in region 3
+      if (in.u8 != 1 || region != 3 || in.items == 0 || in.items > pl->byte_bytes || nn > pl->byte_bytes / in.items ||
+          off > pl->byte_bytes - in.items * nn)
+        return fail(DH_EINVAL);
+      in.dst = pl->bytes + off;
+    }
+  }
   for (const Out& o : pl->outs)
     if (o.C <= 0 || o.ld < o.C || o.npix == 0 || o.npix > arena_f || !fits(o.off, o.npix * nn, (uint64_t)o.ld, (uint64_t)o.C))
       return fail(DH_EINVAL);
@@ -246,6 +277,7 @@ int dh_plan_destroy(dh_plan* pl) {
   if (pl->stream) hipStreamDestroy(pl->stream);
   if (pl->arena) hipFree(pl->arena);
   if (pl->weights) hipFree(pl->weights);
+  if (pl->bytes) hipFree(pl->bytes);
   delete pl;
   return DH_OK;
 }
@@ -256,6 +288,9 @@ int dh_plan_num_outputs(const dh_plan* pl) { return pl ? (int)pl->outs.size() : 
 int64_t dh_plan_input_items(const dh_plan* pl, int i) {
   return (pl && i >= 0 && i < (int)pl->ins.size()) ? (int64_t)pl->ins[i].items : -1;
 }
+int dh_plan_input_is_u8(const dh_plan* pl, int i) {
+  return (pl && i >= 0 && i < (int)pl->ins.size()) ? pl->ins[i].u8 : -1;
+}
 int64_t dh_plan_output_items(const dh_plan* pl, int i) {
   return (pl && i >= 0 && i < (int)pl->outs.size()) ? (int64_t)(pl->outs[i].npix * pl->outs[i].C) : -1;
 }
@@ -265,8 +300,8 @@ int dh_forward(dh_plan* pl, const float* const* inputs, int m, float* const* out
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   for (size_t i = 0; i < pl->ins.size(); ++i) {
     if (inputs[i] == nullptr) return DH_EINVAL;
-    if (hipMemcpyAsync(pl->arena + pl->ins[i].off, inputs[i], pl->ins[i].items * 4 * (size_t)m, hipMemcpyDeviceToDevice,
-                       s) != hipSuccess)
+    const In& in = pl->ins[i];
+    if (hipMemcpyAsync(in.dst, inputs[i], in.items * (in.u8 ? 1 : 4) * (size_t)m, hipMemcpyDeviceToDevice, s) != hipSuccess)
       return DH_ELAUNCH;
   }
   for (const Step& st : pl->steps) {
@@ -293,7 +328,7 @@ int dh_forward_host(dh_plan* pl, const float* const* inputs_host, int m, float* 
     bool ok = hipStreamCreateWithFlags(&st, hipStreamNonBlocking) == hipSuccess;
     for (size_t i = 0; ok && i < pl->ins.size(); ++i) {
       float* q = nullptr;
-      ok = hipMalloc(&q, pl->ins[i].items * 4 * (size_t)pl->n) == hipSuccess;
+      ok = hipMalloc(&q, pl->ins[i].items * (pl->ins[i].u8 ? 1 : 4) * (size_t)pl->n) == hipSuccess;
       if (ok) in_dev.push_back(q);
     }
     for (size_t i = 0; ok && i < pl->outs.size(); ++i) {
@@ -312,8 +347,8 @@ int dh_forward_host(dh_plan* pl, const float* const* inputs_host, int m, float* 
     pl->stream = st;
   }
   for (size_t i = 0; i < pl->ins.size(); ++i)
-    if (hipMemcpyAsync(pl->in_dev[i], inputs_host[i], pl->ins[i].items * 4 * (size_t)m, hipMemcpyHostToDevice,
-                       pl->stream) != hipSuccess)
+    if (hipMemcpyAsync(pl->in_dev[i], inputs_host[i], pl->ins[i].items * (pl->ins[i].u8 ? 1 : 4) * (size_t)m,
+                       hipMemcpyHostToDevice, pl->stream) != hipSuccess)
       return DH_ELAUNCH;
   const int rc = dh_forward(pl, pl->in_dev.data(), m, pl->out_dev.data(), pl->stream);
   if (rc != DH_OK) return rc;

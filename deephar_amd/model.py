@@ -185,12 +185,13 @@ class Model:
         from . import weights as W
         W.save_weights(self, filepath)
 
-    def export_plan(self, filepath, batch_size):
+    def export_plan(self, filepath, batch_size, uint8=False):
         """Write the bound, autotuned launch list + weight image of this model for `batch_size` items: the blob the
         C-level executor of the library runs without Python (dh_plan_create / dh_forward, include/deephar_hip.h;
-        INTEGRATION.md shows a C host).  Returns the number of bytes written."""
+        INTEGRATION.md shows a C host).  uint8=True: the plan takes raw uint8 frames (what `predict` does with uint8
+        arrays: normalised on the GPU with `self.channel_power`).  Returns the number of bytes written."""
         from .engine.serialize import dump_plan
-        blob = dump_plan(self, int(batch_size))
+        blob = dump_plan(self, int(batch_size), u8_norm=self.channel_power if uint8 else None)
         with open(filepath, 'wb') as f:
             f.write(blob)
         return len(blob)

@@ -268,7 +268,10 @@ int dh_depth_from_maps_f32(const float* d, int ldd, const float* h, int ldh, flo
  *            model's input / output order (outputs[i] may be NULL: not wanted); everything is enqueued on `stream`,
  *            nothing synchronises.  Results are bit-identical to Model.predict of the exporting process.
  *   forward_host: the same with HOST pointers (H2D, forward, D2H on an internal stream; returns when done).
- * Float inputs only (uint8 plans are not serialised).  rc != 0 -> the host raises its own error.
+ * uint8-input plans (Model.export_plan(path, batch, uint8=True): raw frames, normalised on the GPU like
+ * utils/transform.normalize_channels, inside the first convolution where possible): dh_plan_input_is_u8(plan, i) == 1 and
+ * inputs[i] points to m * dh_plan_input_items(plan, i) BYTES (cast the uint8 pointer to const float*).
+ * rc != 0 -> the host raises its own error.
  * ------------------------------------------------------------------------------------------------- */
 typedef struct dh_plan dh_plan;
 int dh_plan_create(const void* blob, size_t blob_bytes, dh_plan** plan_out);
@@ -276,7 +279,8 @@ int dh_plan_destroy(dh_plan* plan);
 int dh_plan_batch(const dh_plan* plan);
 int dh_plan_num_inputs(const dh_plan* plan);
 int dh_plan_num_outputs(const dh_plan* plan);
-int64_t dh_plan_input_items(const dh_plan* plan, int i);  /* floats per batch item of input i */
+int64_t dh_plan_input_items(const dh_plan* plan, int i);  /* elements (floats, or bytes of a uint8 input) per batch item */
+int dh_plan_input_is_u8(const dh_plan* plan, int i);      /* 1: input i takes raw uint8 frames, 0: float32, -1: no such input */
 int64_t dh_plan_output_items(const dh_plan* plan, int i); /* floats per batch item of output i */
 int dh_forward(dh_plan* plan, const float* const* inputs_dev, int m, float* const* outputs_dev, void* stream);
 int dh_forward_host(dh_plan* plan, const float* const* inputs_host, int m, float* const* outputs_host);
