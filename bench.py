@@ -503,6 +503,9 @@ def main():
                          'number I of the bound plan(s) --replay-reps times with its in-model arguments and exit; the '
                          'PMC passes of rocprofv3 read the last launches of that kernel')
     ap.add_argument('--replay-reps', type=int, default=4)
+    ap.add_argument('--replay-cfg', type=int, default=None,
+                    help='with --replay-step on a conv step: force this tiling for the replayed launches (bit-identical; '
+                         'lets the PMC passes cover the tilings the autotuner alternates between from box to box)')
     ap.add_argument('--predict-frames', type=int, default=2048,
                     help='frames per Model.predict boundary measurement (SURVEY.md 8d: >= 2 000)')
     args = ap.parse_args()
@@ -607,6 +610,9 @@ def main():
             s_.synchronize()
         calls = [(bp, sp, c) for bp, sp in bound for c in bp.calls]
         bp, sp, (fn, cargs, st) = calls[args.replay_step]
+        if args.replay_cfg is not None and st.kind == 'conv':
+            cargs = (cargs[0], args.replay_cfg)
+            st.attrs['tile_cfg'] = args.replay_cfg
         for _ in range(args.replay_reps):
             rc = fn(*cargs, sp)
             assert rc == 0, rc

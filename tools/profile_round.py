@@ -73,6 +73,45 @@ def pmc_last(db, kernel_sub, last):
     return vals, name
 
 
+def pmc_entry(args, w, base, roof, cfg, kname):
+    """PMC passes over `bench.py --replay-step` of the workload's main-shape launch (tiling `cfg` forced when given)."""
+    head = 'gemm1x1_kernel<4, 1, 1, '
+    sub = ('gemm1x1_kernelILi4ELi1ELi1ELi%sE' % kname[len(head)]) if kname.startswith(head) else kname.split('<')[0]
+    counters, seen_name = {}, None
+    for group in (['FETCH_SIZE', 'SQ_VALU_MFMA_BUSY_CYCLES', 'GRBM_GUI_ACTIVE'], ['WRITE_SIZE']):
+        d = os.path.join(OUT, '%s_pmc_%s_%s' % (args.tag, w, group[0]))
+        sh(['rocprofv3', '--pmc'] + group + ['--kernel-trace', '-d', d, '-o', 'out', '--'] + base + LIGHT +
+           ['--replay-step', str(roof['main_shape_step_index']), '--replay-reps', str(REPS)] +
+           ([] if cfg is None else ['--replay-cfg', str(cfg)]),
+           os.path.join(OUT, '%s_pmc_%s_%s.log' % (args.tag, w, group[0])), cwd='/tmp')
+        db = find_db(d)
+        if db:
+            vals, name = pmc_last(db, sub, REPS)
+            counters.update(vals)
+            seen_name = name or seen_name
+        subprocess.call(['rm', '-rf', d])
+    if not {'FETCH_SIZE', 'WRITE_SIZE'} <= set(counters):
+        print('PMC incomplete for', w, kname, counters)
+        return None
+    e = dict(workload=w, kernel=kname, mangled=seen_name, shape_mkn=roof['main_shape_mkn'],
+             epilogue=roof['main_shape_epilogue'], step_index=roof['main_shape_step_index'],
+             algorithmic_bytes_per_launch=roof['algorithmic_bytes_per_launch'],
+             fetch_bytes_per_launch=int(2 * 1024 * counters['FETCH_SIZE']),
+             write_bytes_per_launch=int(1024 * counters['WRITE_SIZE']),
+             raw_counters_per_launch={k: round(v, 1) for k, v in counters.items()},
+             source='rocprofv3 --pmc, FETCH_SIZE(+MFMA busy, GUI active) and WRITE_SIZE in separate passes over `python '
+                    'bench.py --workload %s --replay-step %d%s` (tools/profile_round.py): the last %d dispatches = the '
+                    'in-model launch replayed; FETCH_SIZE / WRITE_SIZE are KiB, FETCH_SIZE x2 on gfx950 '
+                    '(MI355X_MICROARCH.md, HBM section)' % (w, roof['main_shape_step_index'],
+                                                            '' if cfg is None else ' --replay-cfg %d' % cfg, REPS))
+    e['traffic_over_algorithmic'] = round((e['fetch_bytes_per_launch'] + e['write_bytes_per_launch']) /
+                                          e['algorithmic_bytes_per_launch'], 4)
+    if 'SQ_VALU_MFMA_BUSY_CYCLES' in counters and counters.get('GRBM_GUI_ACTIVE'):
+        # busy cycles are summed over 1024 SIMDs; GRBM_GUI_ACTIVE over the 8 XCDs
+        e['mfma_busy_fraction'] = round(counters['SQ_VALU_MFMA_BUSY_CYCLES'] / 1024.0 / (counters['GRBM_GUI_ACTIVE'] / 8.0), 4)
+    return e
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('tag')
@@ -116,40 +155,19 @@ def main():
         # (3) PMC passes over the in-model launch of the main shape
         if args.skip_pmc:
             continue
-        sub = roof['kernel'].split('<')[0]
-        counters = {}
-        seen_name = None
-        for group in (['FETCH_SIZE', 'SQ_VALU_MFMA_BUSY_CYCLES', 'GRBM_GUI_ACTIVE'], ['WRITE_SIZE']):
-            d = os.path.join(OUT, '%s_pmc_%s_%s' % (args.tag, w, group[0]))
-            sh(['rocprofv3', '--pmc'] + group + ['--kernel-trace', '-d', d, '-o', 'out', '--'] + base + LIGHT +
-               ['--replay-step', str(roof['main_shape_step_index']), '--replay-reps', str(REPS)],
-               os.path.join(OUT, '%s_pmc_%s_%s.log' % (args.tag, w, group[0])), cwd='/tmp')
-            db = find_db(d)
-            if db:
-                vals, name = pmc_last(db, sub, REPS)
-                counters.update(vals)
-                seen_name = name or seen_name
-            subprocess.call(['rm', '-rf', d])
-        if not {'FETCH_SIZE', 'WRITE_SIZE'} <= set(counters):
-            print('PMC incomplete for', w, counters)
-            continue
-        e = dict(workload=w, kernel=roof['kernel'], mangled=seen_name, shape_mkn=roof['main_shape_mkn'],
-                 epilogue=roof['main_shape_epilogue'], step_index=roof['main_shape_step_index'],
-                 algorithmic_bytes_per_launch=roof['algorithmic_bytes_per_launch'],
-                 fetch_bytes_per_launch=int(2 * 1024 * counters['FETCH_SIZE']),
-                 write_bytes_per_launch=int(1024 * counters['WRITE_SIZE']),
-                 raw_counters_per_launch={k: round(v, 1) for k, v in counters.items()},
-                 source='rocprofv3 --pmc, FETCH_SIZE(+MFMA busy, GUI active) and WRITE_SIZE in separate passes over `python '
-                        'bench.py --workload %s --replay-step %d` (tools/profile_round.py): the last %d dispatches = the '
-                        'in-model launch replayed; FETCH_SIZE / WRITE_SIZE are KiB, FETCH_SIZE x2 on gfx950 '
-                        '(MI355X_MICROARCH.md, HBM section)' % (w, roof['main_shape_step_index'], REPS))
-        e['traffic_over_algorithmic'] = round((e['fetch_bytes_per_launch'] + e['write_bytes_per_launch']) /
-                                              e['algorithmic_bytes_per_launch'], 4)
-        if 'SQ_VALU_MFMA_BUSY_CYCLES' in counters and counters.get('GRBM_GUI_ACTIVE'):
-            # busy cycles are summed over 1024 SIMDs; GRBM_GUI_ACTIVE over the 8 XCDs
-            e['mfma_busy_fraction'] = round(counters['SQ_VALU_MFMA_BUSY_CYCLES'] / 1024.0 / (counters['GRBM_GUI_ACTIVE'] / 8.0), 4)
-        entries.append(e)
-        print(json.dumps(e), flush=True)
+        # the autotuner alternates between near-equal tilings of the dominant pointwise GEMM from box to box: cover both
+        variants = [(None, roof['kernel'])]
+        head = 'gemm1x1_kernel<4, 1, 1, '
+        if roof['kernel'].startswith(head):
+            tn = roof['kernel'][len(head)]
+            other = {'3': (12, '2'), '2': (11, '3')}.get(tn)
+            if other:
+                variants.append((other[0], roof['kernel'].replace(head + tn, head + other[1], 1)))
+        for cfg, kname in variants:
+            e = pmc_entry(args, w, base, roof, cfg, kname)
+            if e is not None:
+                entries.append(e)
+                print(json.dumps(e), flush=True)
     if entries:
         with open(os.path.join(OUT, '%s_pmc_dominant_kernel.json' % args.tag), 'w') as f:
             json.dump(dict(launches=entries), f, indent=1)
