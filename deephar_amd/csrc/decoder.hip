@@ -376,6 +376,65 @@ __global__ __launch_bounds__(NTH) void depth_means_z_kernel(const float* __restr
   }
 }
 
+// Both means in ONE pass over the maps [r04]: the 3-D head reads its 16 x J depth-joint maps twice (once per mean; at
+// batch 128 that tensor is 142 MB, the two launches were 2.6 % of the Human3.6M step).  Work-group = one frame, 512
+// threads, walking chunks of 64 pixels: the chunk goes to LDS with 16-byte loads (the next chunk's loads are in flight
+// during the arithmetic), hxy of its pixels is summed over depth out of LDS, and thread c keeps the running pixel sum of
+// channel c in four interleaved accumulators -- pixels in ascending order, so the result does not depend on the launch.
+constexpr int DM_NT = 512, DM_PX = 64, DM_MAXC = 288;
+__global__ __launch_bounds__(DM_NT) void depth_means_fused_kernel(const float* __restrict__ h, int ldh, float* __restrict__ hxy,
+                                                                 float* __restrict__ hz, int HW, int D, int J) {
+  extern __shared__ __attribute__((aligned(16))) float dm_lds[];      // [DM_PX][DJ]
+  const int tid = threadIdx.x, f = blockIdx.x;
+  const int DJ = D * J, c4n = DJ >> 2;
+  const float* src = h + (size_t)f * HW * ldh;
+  constexpr int NL = (DM_PX * (DM_MAXC / 4) + DM_NT - 1) / DM_NT;     // float4 loads per thread and chunk (9)
+  const unsigned magic = (1u << 20) / (unsigned)c4n + 1u;             // i / c4n for i < 64 * 72
+  float4 stage[NL];
+  auto fetch = [&](int p0) {
+#pragma unroll
+    for (int k = 0; k < NL; ++k) {
+      const int i = tid + k * DM_NT;
+      const int px = (int)(((unsigned)i * magic) >> 20), q = i - px * c4n;
+      const bool ok = i < DM_PX * c4n && p0 + px < HW;
+      stage[k] = ok ? *reinterpret_cast<const float4*>(src + (size_t)(p0 + px) * ldh + q * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  };
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+  const float invd = 1.f / (float)D;
+  fetch(0);
+  for (int p0 = 0; p0 < HW; p0 += DM_PX) {
+#pragma unroll
+    for (int k = 0; k < NL; ++k) {
+      const int i = tid + k * DM_NT;
+      if (i < DM_PX * c4n) reinterpret_cast<float4*>(dm_lds)[i] = stage[k];
+    }
+    __syncthreads();
+    if (p0 + DM_PX < HW) fetch(p0 + DM_PX);
+    const int npx = HW - p0 < DM_PX ? HW - p0 : DM_PX;
+    for (int it = tid; it < npx * J; it += DM_NT) {                   // hxy[f, p, j] = mean_d h[f, p, d * J + j]
+      const int px = it / J, j = it - px * J;
+      const float* row = dm_lds + px * DJ + j;
+      float acc = 0.f;
+      for (int d = 0; d < D; ++d) acc += row[d * J];
+      hxy[((size_t)f * HW + p0 + px) * J + j] = acc * invd;
+    }
+    if (tid < DJ) {                                                   // hz[f, c] += sum over the chunk's pixels
+      const float* col = dm_lds + tid;
+      int px = 0;
+      for (; px + 3 < npx; px += 4) {
+        a0 += col[px * DJ];
+        a1 += col[(px + 1) * DJ];
+        a2 += col[(px + 2) * DJ];
+        a3 += col[(px + 3) * DJ];
+      }
+      for (; px < npx; ++px) a0 += col[px * DJ];
+    }
+    __syncthreads();
+  }
+  if (tid < DJ) hz[(size_t)f * DJ + tid] = ((a0 + a1) + (a2 + a3)) * (1.f / (float)HW);
+}
+
 __global__ __launch_bounds__(256) void softargmax1d_kernel(const float* __restrict__ hz,
                                                            const float* __restrict__ grid,
                                                            float* __restrict__ z, int ldz,
@@ -645,6 +704,15 @@ int launch_context_agg(const float* ys, const float* yc, const float* pc, float*
 int launch_depth_means(const float* h, int ldh, float* hxy, float* hz, int F, int HW, int D, int J,
                        hipStream_t s) {
   if (F <= 0 || HW <= 0 || D <= 0 || J <= 0) return DH_EINVAL;
+  const int DJ = D * J;
+  if (hxy != nullptr && hz != nullptr && DJ % 4 == 0 && DJ <= DM_MAXC && ldh % 4 == 0 && DJ <= DM_NT &&
+      (reinterpret_cast<uintptr_t>(h) & 15) == 0) {                    // both means of the same maps: one pass
+    const size_t lds = (size_t)DM_PX * DJ * sizeof(float);
+    static LdsLimit lim;
+    lim.raise((const void*)depth_means_fused_kernel, (int)(DM_PX * DM_MAXC * sizeof(float)));
+    hipLaunchKernelGGL(depth_means_fused_kernel, dim3((unsigned)F), dim3(DM_NT), lds, s, h, ldh, hxy, hz, HW, D, J);
+    return check_launch();
+  }
   if (hxy != nullptr) {
     long long g = ((long long)F * HW * J + 255) / 256;
     if (g > 4096) g = 4096;

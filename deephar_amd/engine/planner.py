@@ -783,12 +783,20 @@ class Planner:
         self.val[node.outputs[0].uid] = y
 
     def op_depthmean(self, node):
+        """reception.pose_regression_3d (reception.py:193-222) takes the mean of the same D x J maps over depth and over
+        the pixels: both read-outs are one launch (one pass over the maps) when both nodes hang on the same tensor."""
         h = self.materialize(node.inputs[0])
-        y = self.new_value(node.outputs[0].shape)
-        role = 'hxy' if node.attrs['axis'] == 'd' else 'hz'
-        self.emit('depth_means', dict(h=h), {role: y}, dict(D=node.attrs['D'], J=node.attrs['J']),
-                  name='depth_means_' + role)
-        self.val[node.outputs[0].uid] = y
+        role_of = lambda n: 'hxy' if n.attrs['axis'] == 'd' else 'hz'
+        outs = {role_of(node): self.new_value(node.outputs[0].shape)}
+        self.val[node.outputs[0].uid] = outs[role_of(node)]
+        for n, _ in self.consumers.get(node.inputs[0].uid, []):
+            if n is not node and n.op == 'depthmean' and n.uid not in self.absorbed and n.uid not in self.processed and \
+                    role_of(n) not in outs and (n.attrs['D'], n.attrs['J']) == (node.attrs['D'], node.attrs['J']):
+                outs[role_of(n)] = self.new_value(n.outputs[0].shape)
+                self.val[n.outputs[0].uid] = outs[role_of(n)]
+                self.absorbed.add(n.uid)
+        self.emit('depth_means', dict(h=h), outs, dict(D=node.attrs['D'], J=node.attrs['J']),
+                  name='depth_means_' + '_'.join(sorted(outs)))
 
     def op_softargmax1d(self, node):
         hz = self.materialize(node.inputs[0])
