@@ -24,8 +24,9 @@ Rank 0 prints ONE JSON line, which also carries
                  algorithmic FLOPs per launch (from the plan: 2 * M * K * Cout) / average launch duration, measured
                  with HIP events on the launch stream in an eager pass right after the timed region (kernels inside
                  a replayed hipGraph cannot be bracketed); peak = 157.3 TFLOP/s fp32 MFMA (MI355X_MICROARCH.md);
-                 `traffic` = HBM bytes per launch from the separate rocprofv3 --pmc passes of THE SAME instantiation
-                 and shape (profiles/pmc_dominant_kernel.json, written by tools/profile_round.sh), else null.
+                 `traffic` = HBM bytes per launch from the separate rocprofv3 --pmc passes over THE SAME launch --
+                 instantiation, M x K x N and epilogue (profiles/pmc_dominant_kernel.json, written by
+                 tools/profile_round.py from `bench.py --replay-step`), else null.
   predict_fps  : (mpii, N=1) what a caller of Model.predict gets -- host numpy arrays in, host arrays out, wall clock
                  over 2 048 frames after one warm-up call (method of exp/pennaction/eval_speed2d.py:70-77), for float32
                  frames and for raw uint8 frames (normalised inside the first convolution).  Never `value`.
