@@ -185,7 +185,7 @@ class Planner:
             prods.sort(key=lambda t: index[t.node.uid])
             others = [t for t in n.inputs if all(t.uid != q.uid for q in prods)]
             pos = lambda t: index[t.node.uid] if t.node is not None and t.node.uid in index else -1
-            partial, chain = None, []
+            partial = None
             for k, p in enumerate(prods):
                 last = k == len(prods) - 1
                 take = [partial] if partial is not None else []
@@ -204,7 +204,6 @@ class Planner:
                 else:
                     insert_after.setdefault(p.node.uid, []).append(node)
                 partial = node.outputs[0]
-                chain.append(node)
         if not replace:
             return nodes
         out = []
