@@ -248,6 +248,26 @@ class ShardedClipModel:
         self.last_outputs = outs
         return outs
 
+    def export_plans(self, prefix, clips, uint8=False):
+        """Write the two stages as C-level plans (include/deephar_hip.h: dh_plan_create / dh_forward) for `clips` clips per
+        step: '<prefix>.frames.dhplan' takes this rank's [clips, T/G, H, W, C] frames and returns ONE packed
+        [clips, T/G, J, Cp] tensor; '<prefix>.head.dhplan' takes the cut tensors at full T -- channel runs of the gathered
+        buffer, `info['cut']` = [(shape, channel offset, channels)] -- in that order and returns the outputs
+        `info['head_outputs']`; `info['passthrough']` maps the remaining model outputs to cut tensors.  A host without Python
+        runs: frame plan -> its own all-gather of the packed tensor over the ranks (rank-major) -> head plan.  Returns
+        `info` (a JSON-able dict is also written to '<prefix>.cut.json')."""
+        import json
+        self.frame_model.export_plan(prefix + '.frames.dhplan', clips, uint8=uint8)
+        if self.head_model is not None:
+            self.head_model.export_plan(prefix + '.head.dhplan', clips)
+        info = dict(world=self.world, T=self.info['T'], Tl=self.info['Tl'], packed_channels=self.info['packed_channels'],
+                    cut=[dict(shape=list(s), offset=o, channels=c) for (s, o, c) in self.info['cut']],
+                    passthrough={str(k): v for k, v in self.info['passthrough'].items()},
+                    head_outputs=list(self.info['head_outputs']))
+        with open(prefix + '.cut.json', 'w') as f:
+            json.dump(info, f)
+        return info
+
     def predict(self, clips):
         """clips: [N, T, H, W, C] (the same array on every rank).  Returns the model's outputs (host arrays)."""
         info = self.info
