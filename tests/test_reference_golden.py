@@ -78,3 +78,29 @@ def test_keras_parity_kit_round_trip(tmp_path):
     g32, _ = golden('rec2d')
     for i, a in enumerate(g32):
         assert np.array_equal(out['rec2d/%d' % i], a)
+
+
+def test_oracle_runs_a_pose_only_spnet_on_single_frames():
+    """exp/pennaction/predict_bboxes.py:35-41, exp/ntu/predict_bboxes.py:35-41: SPNet built on single frames with
+    `action_pyramids=[]` (pose only).  The oracle takes that configuration (it used to take max() of the empty list), its
+    output count and shapes are the builder's, frames are independent, and the last pose is what `Model(full.input,
+    full.outputs[-1])` re-wraps."""
+    from deephar_amd import Model, graph, utils, weights
+    from deephar_amd.config import ModelConfig
+    from deephar_amd.models import spnet
+    from oracle import spnet as osp
+    graph.reset_naming()
+    cfg = ModelConfig((64, 64, 3), utils.pa16j2d, num_pyramids=2, action_pyramids=[], num_levels=3)
+    full = spnet.build(cfg)
+    weights.init_synthetic(full, seed=0)
+    one = Model(full.input, full.outputs[-1])
+    assert len(one.outputs) == 1 and one.outputs[0].shape == (16, 3)
+    ocfg = dict(num_joints=16, dim=2, num_actions=[], num_pyramids=2, action_pyramids=[], num_levels=3, kernel_size=(5, 5),
+                growth=96, image_div=8, num_pose_features=0, num_visual_features=0, sam_alpha=1)
+    x = np.random.default_rng(3).uniform(-1, 1, (3, 64, 64, 3)).astype(np.float32)
+    outs = osp.forward(weights.as_dict(full), x, ocfg)
+    assert len(outs) == len(full.outputs) == spnet.get_num_predictions(2, 3)
+    assert all(o.shape == (3,) + t.shape for o, t in zip(outs, full.outputs))
+    again = osp.forward(weights.as_dict(full), x[::-1].copy(), ocfg)
+    assert np.allclose(again[-1][::-1], outs[-1], atol=1e-6)
+    assert np.all(np.isfinite(outs[-1])) and outs[-1][..., :2].min() >= 0 and outs[-1][..., :2].max() <= 1
