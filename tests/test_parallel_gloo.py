@@ -98,7 +98,7 @@ def _host_cost_worker(rank, world, port, q):
         from deephar_amd import parallel
         m, _ = _build()
         runner = parallel.ShardedClipModel(m, frame_fn=None, head_fn=None)
-        n, tl, cp = 4, runner.info['Tl'], runner.info['packed_channels']
+        n, tl, cp = 1, runner.info["Tl"], runner.info["packed_channels"]    # (one clip: the stand-in path copies the parts)
         packed = torch.zeros((n, tl, J, cp))
         head_out = [torch.zeros((n, NACT)) for _ in runner.info['head_outputs']]
         runner.frame_fn = lambda x: packed
