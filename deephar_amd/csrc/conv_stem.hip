@@ -10,7 +10,7 @@
 //   * im2col happens in the fragment ADDRESS: for a fixed kernel row kh the taps (kw, c) of an output pixel are KW * 3
 //     CONSECUTIVE floats of the LDS row starting at pixel 2 * ow, so lane (li, lh) reads A[row li][k = 2j + lh] of MFMA j
 //     with one ds_read_b32 at an immediate offset; KW * 3 is padded to even with a zero weight (the extra float read is
-//     a neighbouring, finite input value);
+//     a neighbouring input value, replaced by 0 in the pad lane);
 //   * the weights [KH][KW*3 (+pad)][Cout] are staged into LDS once per work-group from the standard packed layout
 //     ([Kp/4][Np][4], K = (kh, kw, c)): no second weight packing;
 //   * K runs (kh, kw, c) ascending, two consecutive k per MFMA; the tap-major kernels pair k with k + 4 inside blocks of
@@ -60,6 +60,44 @@ __global__ __launch_bounds__(256, 2) void conv_stem_kernel(const ConvArgs p, con
   const size_t frame = (size_t)n * p.H * p.W * C;        // element offset of the frame (floats or bytes)
   const int row_elems = p.W * C;
 
+  // ---- halo: HR rows x RP floats, a linear copy of the image rows with zeros outside the image.  [r05] The copy of row
+  // pair pr + 1 is issued into registers BEFORE the MFMA block of pair pr and lands in LDS after it: the global round trip
+  // runs under the matrix work (round 4 waited for it between two barriers; the SPNet first layer sat at 0.55).
+  constexpr int NE = (HR * RP + 255) / 256;              // fully unrolled: every load of the copy is in flight at once
+  float stg[U8 ? 1 : NE];                                // float frames: the value (0 outside the image)
+  int sti[U8 ? NE : 1];                                  // uint8 frames: index into the normalisation table, -1 outside
+  auto issue = [&](int pr) {
+    const int ih0 = (pair0 + pr) * 4 - p.PT;
+#pragma unroll
+    for (int q = 0; q < NE; ++q) {
+      const int e = tid + q * 256;
+      if (e >= HR * RP) break;
+      const int r = e / RP, f = e - r * RP;
+      const int ih = ih0 + r, fo = f - C * p.PL;
+      const bool ok = f < RF && (unsigned)ih < (unsigned)p.H && (unsigned)fo < (unsigned)row_elems;
+      const size_t off = frame + (size_t)(ok ? ih : 0) * row_elems + (ok ? fo : 0);
+      if constexpr (U8) {
+        const int ch = (fo + 3 * 64) % 3;                // (fo >= -3 * PL > -192)
+        const int b = reinterpret_cast<const unsigned char*>(p.x)[off];
+        sti[q] = ok ? ch * 256 + b : -1;
+      } else {
+        const float v = p.x[off];
+        stg[q] = ok ? v : 0.f;
+      }
+    }
+  };
+  auto land = [&]() {
+#pragma unroll
+    for (int q = 0; q < NE; ++q) {
+      const int e = tid + q * 256;
+      if (e >= HR * RP) break;
+      if constexpr (U8) halo[e] = sti[q] >= 0 ? lut[sti[q]] : 0.f;
+      else halo[e] = stg[q];
+    }
+  };
+  issue(0);
+  __syncthreads();                                       // weights and table staged (the table is read by land())
+
   // ---- fragment addresses (float indices), fixed over the row pairs
   int a_base[2];
 #pragma unroll
@@ -79,28 +117,10 @@ __global__ __launch_bounds__(256, 2) void conv_stem_kernel(const ConvArgs p, con
 
   for (int pr = 0; pr < pairs_per_wg; ++pr) {
     const int oh0 = (pair0 + pr) * 2;
-    const int ih0 = oh0 * 2 - p.PT;
     if (pr > 0) __syncthreads();                         // every wave is done reading the previous halo
-    // ---- halo: HR rows x RP floats, a linear copy of the image rows with zeros outside the image
-    constexpr int NE = (HR * RP + 255) / 256;            // fully unrolled: every load of the copy is in flight at once
-#pragma unroll
-    for (int q = 0; q < NE; ++q) {
-      const int e = tid + q * 256;
-      if (e >= HR * RP) break;
-      const int r = e / RP, f = e - r * RP;
-      const int ih = ih0 + r, fo = f - C * p.PL;
-      const bool ok = f < RF && (unsigned)ih < (unsigned)p.H && (unsigned)fo < (unsigned)row_elems;
-      const size_t off = frame + (size_t)(ok ? ih : 0) * row_elems + (ok ? fo : 0);
-      float v;
-      if constexpr (U8) {
-        const int ch = (fo + 3 * 64) % 3;                // (fo >= -3 * PL > -192)
-        v = lut[ch * 256 + reinterpret_cast<const unsigned char*>(p.x)[off]];
-      } else {
-        v = p.x[off];
-      }
-      halo[e] = ok ? v : 0.f;
-    }
+    land();
     __syncthreads();
+    if (pr + 1 < pairs_per_wg) issue(pr + 1);
 
     f32x16 acc[2][TN];
 #pragma unroll
@@ -115,7 +135,10 @@ __global__ __launch_bounds__(256, 2) void conv_stem_kernel(const ConvArgs p, con
       for (int j = 0; j < NJ; ++j) {
         float a[2], b[TN];
 #pragma unroll
-        for (int i = 0; i < 2; ++i) a[i] = halo[a_base[i] + kh * RP + 2 * j];
+        for (int i = 0; i < 2; ++i) {
+          a[i] = halo[a_base[i] + kh * RP + 2 * j];
+          if ((KL & 1) && j == NJ - 1) a[i] = lh ? 0.f : a[i];       // the K pad slot holds a neighbouring input value: an Inf / NaN
+        }                                                            // there must not reach this output through 0 * x
 #pragma unroll
         for (int t = 0; t < TN; ++t) b[t] = Bs[b_base + (kh * KLP + 2 * j) * BN + t * 32];
 #pragma unroll

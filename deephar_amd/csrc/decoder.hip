@@ -322,9 +322,30 @@ __global__ __launch_bounds__(256) void context_agg_kernel(const float* __restric
   y[(size_t)idx * ldy + 1] = alpha * ysv + (1.f - alpha) * (spy / sp);
 }
 
-// hxy[f,p,j] = mean_d h[f,p,d*J+j]; hz[f,d,j] = mean_p h[f,p,d*J+j]
-// grid = (F, chunks of pixels); thread = channel (d*J+j) for hz partials via atomics-free two-stage:
-// stage A (this kernel, blockIdx.y = pixel chunk): hxy directly; hz partial sums into hz_part.
+// hxy[f,p,j] = mean_d h[f,p,d*J+j]; hz[f,d,j] = mean_p h[f,p,d*J+j]   (reception.py:193-222)
+//
+// ONE summation order for every kernel below [r05], so the launcher may pick by batch size without moving a bit:
+//   hxy: four accumulators over d (d & 3), then (a0 + a1) + (a2 + a3), times 1/D;
+//   hz : the pixels are cut into chunks of 64 (missing pixels of a ragged last chunk count as 0).  Inside chunk k the
+//        quad sums q[k][l] = (v[4l] + v[4l+1]) + (v[4l+2] + v[4l+3]), l = 0..15; each l accumulates its q over the
+//        chunks in ascending k (P[l]); the sixteen P[l] are summed as a balanced tree pairing l with l^1, l^2, l^4, l^8;
+//        times 1/HW.  Rounding depth: 2 + HW/64 + 4 additions (22 for 32 x 32 maps) -- round 4's one-pass kernel ran
+//        256 serial additions per accumulator and cost the 3-D head two thirds of its parity margin.
+__device__ __forceinline__ float depth_mean_d(const float* __restrict__ src, int D, int J, float invd) {
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+  int d = 0;
+  for (; d + 3 < D; d += 4) {
+    a0 += src[d * J];
+    a1 += src[(d + 1) * J];
+    a2 += src[(d + 2) * J];
+    a3 += src[(d + 3) * J];
+  }
+  if (d < D) a0 += src[d * J];
+  if (d + 1 < D) a1 += src[(d + 1) * J];
+  if (d + 2 < D) a2 += src[(d + 2) * J];
+  return ((a0 + a1) + (a2 + a3)) * invd;
+}
+
 __global__ __launch_bounds__(256) void depth_means_xy_kernel(const float* __restrict__ h, int ldh,
                                                              float* __restrict__ hxy, int F, int HW, int D,
                                                              int J) {
@@ -334,17 +355,13 @@ __global__ __launch_bounds__(256) void depth_means_xy_kernel(const float* __rest
        idx += (long long)gridDim.x * blockDim.x) {
     const int j = (int)(idx % J);
     const long long px = idx / J;
-    const float* src = h + px * ldh + j;
-    float acc = 0.f;
-    for (int d = 0; d < D; ++d) acc += src[d * J];
-    hxy[idx] = acc * invd;
+    hxy[idx] = depth_mean_d(h + px * ldh + j, D, J, invd);
   }
 }
 
-// hz[f, c] = mean over the pixels of h[f, :, c], c over the D * J depth-joint channels.  Work-group = (frame, group of
-// CG channels), thread = (channel, pixel lane) like the soft-argmax kernel: 16 pixel lanes x four loads in flight, summed
-// through the wave and LDS.  (One work-group per frame walking its 1024 pixels serially took 132 us for the H36M head,
-// 64 x 1024 x 272; this form reads the 71 MB once at HBM speed.)
+// hz for small batches: work-group = (frame, group of CG channels), thread = (channel, quad lane l): F * DJ / 16
+// work-groups where the one-pass kernel below has F.  The tree over l runs xor 16, xor 32 inside the wave (l = tid / 16:
+// l^1 and l^2 are lanes of the same wave) and (r0 + r1) + (r2 + r3) across the four waves through LDS.
 __global__ __launch_bounds__(NTH) void depth_means_z_kernel(const float* __restrict__ h, int ldh,
                                                             float* __restrict__ hz, int HW, int DJ) {
   __shared__ float red[NW][CG];
@@ -353,35 +370,30 @@ __global__ __launch_bounds__(NTH) void depth_means_z_kernel(const float* __restr
   const int groups = (DJ + CG - 1) / CG;
   const int f = blockIdx.x / groups;
   const int c = (blockIdx.x % groups) * CG + cc;
-  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+  float acc = 0.f;
   if (c < DJ) {
     const float* src = h + (size_t)f * HW * ldh + c;
-    int px = pl;
-    for (; px + 3 * PL < HW; px += 4 * PL) {
-      a0 += src[(size_t)px * ldh];
-      a1 += src[(size_t)(px + PL) * ldh];
-      a2 += src[(size_t)(px + 2 * PL) * ldh];
-      a3 += src[(size_t)(px + 3 * PL) * ldh];
+    for (int p0 = 4 * pl; p0 < HW; p0 += 64) {
+      const float v0 = src[(size_t)p0 * ldh];
+      const float v1 = p0 + 1 < HW ? src[(size_t)(p0 + 1) * ldh] : 0.f;
+      const float v2 = p0 + 2 < HW ? src[(size_t)(p0 + 2) * ldh] : 0.f;
+      const float v3 = p0 + 3 < HW ? src[(size_t)(p0 + 3) * ldh] : 0.f;
+      acc += (v0 + v1) + (v2 + v3);
     }
-    for (; px < HW; px += PL) a0 += src[(size_t)px * ldh];
   }
-  float acc = wave_sum_cg((a0 + a1) + (a2 + a3));
+  acc += __shfl_xor(acc, 16);
+  acc += __shfl_xor(acc, 32);
   if ((tid & 63) < CG) red[tid >> 6][cc] = acc;
   __syncthreads();
-  if (tid < CG && c < DJ) {
-    float t = red[0][cc];
-#pragma unroll
-    for (int w = 1; w < NW; ++w) t += red[w][cc];
-    hz[(size_t)f * DJ + c] = t * (1.f / (float)HW);
-  }
+  if (tid < CG && c < DJ) hz[(size_t)f * DJ + c] = ((red[0][cc] + red[1][cc]) + (red[2][cc] + red[3][cc])) * (1.f / (float)HW);
 }
 
 // Both means in ONE pass over the maps [r04]: the 3-D head reads its 16 x J depth-joint maps twice (once per mean; at
 // batch 128 that tensor is 142 MB, the two launches were 2.6 % of the Human3.6M step).  Work-group = one frame, 512
 // threads, walking chunks of 64 pixels: the chunk goes to LDS with 16-byte loads (the next chunk's loads are in flight
-// during the arithmetic), hxy of its pixels is summed over depth out of LDS, and thread c keeps the running pixel sum of
-// channel c in four interleaved accumulators -- pixels in ascending order, so the result does not depend on the launch.
-constexpr int DM_NT = 512, DM_PX = 64, DM_MAXC = 288;
+// during the arithmetic), hxy of its pixels is summed over depth out of LDS, and thread c keeps the sixteen running quad
+// sums P[l] of channel c [r05: the order stated above, bit-identical to the two kernels above].
+constexpr int DM_NT = 512, DM_PX = 64, DM_MAXC = 288, DM_MIN_FRAMES = 96;
 __global__ __launch_bounds__(DM_NT) void depth_means_fused_kernel(const float* __restrict__ h, int ldh, float* __restrict__ hxy,
                                                                  float* __restrict__ hz, int HW, int D, int J) {
   extern __shared__ __attribute__((aligned(16))) float dm_lds[];      // [DM_PX][DJ]
@@ -400,39 +412,39 @@ __global__ __launch_bounds__(DM_NT) void depth_means_fused_kernel(const float* _
       stage[k] = ok ? *reinterpret_cast<const float4*>(src + (size_t)(p0 + px) * ldh + q * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
   };
-  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+  float P[16];
+#pragma unroll
+  for (int l = 0; l < 16; ++l) P[l] = 0.f;
   const float invd = 1.f / (float)D;
   fetch(0);
   for (int p0 = 0; p0 < HW; p0 += DM_PX) {
 #pragma unroll
     for (int k = 0; k < NL; ++k) {
       const int i = tid + k * DM_NT;
-      if (i < DM_PX * c4n) reinterpret_cast<float4*>(dm_lds)[i] = stage[k];
+      if (i < DM_PX * c4n) reinterpret_cast<float4*>(dm_lds)[i] = stage[k];   // pixels past HW arrive as zeros
     }
     __syncthreads();
     if (p0 + DM_PX < HW) fetch(p0 + DM_PX);
     const int npx = HW - p0 < DM_PX ? HW - p0 : DM_PX;
     for (int it = tid; it < npx * J; it += DM_NT) {                   // hxy[f, p, j] = mean_d h[f, p, d * J + j]
       const int px = it / J, j = it - px * J;
-      const float* row = dm_lds + px * DJ + j;
-      float acc = 0.f;
-      for (int d = 0; d < D; ++d) acc += row[d * J];
-      hxy[((size_t)f * HW + p0 + px) * J + j] = acc * invd;
+      hxy[((size_t)f * HW + p0 + px) * J + j] = depth_mean_d(dm_lds + px * DJ + j, D, J, invd);
     }
-    if (tid < DJ) {                                                   // hz[f, c] += sum over the chunk's pixels
+    if (tid < DJ) {                                                   // P[l] += quad sum l of the chunk
       const float* col = dm_lds + tid;
-      int px = 0;
-      for (; px + 3 < npx; px += 4) {
-        a0 += col[px * DJ];
-        a1 += col[(px + 1) * DJ];
-        a2 += col[(px + 2) * DJ];
-        a3 += col[(px + 3) * DJ];
-      }
-      for (; px < npx; ++px) a0 += col[px * DJ];
+#pragma unroll
+      for (int l = 0; l < 16; ++l)
+        P[l] += (col[(4 * l) * DJ] + col[(4 * l + 1) * DJ]) + (col[(4 * l + 2) * DJ] + col[(4 * l + 3) * DJ]);
     }
     __syncthreads();
   }
-  if (tid < DJ) hz[(size_t)f * DJ + tid] = ((a0 + a1) + (a2 + a3)) * (1.f / (float)HW);
+  if (tid < DJ) {
+#pragma unroll
+    for (int s = 1; s < 16; s <<= 1)
+#pragma unroll
+      for (int l = 0; l < 16; l += 2 * s) P[l] += P[l + s];
+    hz[(size_t)f * DJ + tid] = P[0] * (1.f / (float)HW);
+  }
 }
 
 __global__ __launch_bounds__(256) void softargmax1d_kernel(const float* __restrict__ hz,
@@ -705,7 +717,9 @@ int launch_depth_means(const float* h, int ldh, float* hxy, float* hz, int F, in
                        hipStream_t s) {
   if (F <= 0 || HW <= 0 || D <= 0 || J <= 0) return DH_EINVAL;
   const int DJ = D * J;
-  if (hxy != nullptr && hz != nullptr && DJ % 4 == 0 && DJ <= DM_MAXC && ldh % 4 == 0 && DJ <= DM_NT &&
+  // One work-group per frame: the one-pass kernel needs about as many frames as the chip has CUs; below
+  // that the two kernels with F * groups work-groups run -- same bits (one summation order), so the choice is free.
+  if (hxy != nullptr && hz != nullptr && DJ % 4 == 0 && DJ <= DM_MAXC && ldh % 4 == 0 && DJ <= DM_NT && F >= DM_MIN_FRAMES &&
       (reinterpret_cast<uintptr_t>(h) & 15) == 0) {                    // both means of the same maps: one pass
     const size_t lds = (size_t)DM_PX * DJ * sizeof(float);
     static LdsLimit lim;

@@ -463,7 +463,6 @@ class BoundPlan:
         if self.plan.nstreams > 1:
             if _MULTISTREAM_GRAPHS >= MAX_MULTISTREAM_GRAPHS:
                 return False
-            _MULTISTREAM_GRAPHS += 1
         _lib.check(lib.dh_graph_begin_capture(stream_ptr), 'graph capture begin')
         try:
             self.launch_all(stream_ptr)
@@ -472,6 +471,8 @@ class BoundPlan:
             rc = lib.dh_graph_end_capture(stream_ptr, C.byref(g))
         _lib.check(rc, 'graph capture end')
         self.graph = g
+        if self.plan.nstreams > 1:
+            _MULTISTREAM_GRAPHS += 1      # counted only once a graph exec exists (a failed capture holds no slot: ADVICE r04)
         return True
 
     def replay(self, stream_ptr):

@@ -118,6 +118,7 @@ class Plan:
         self.params = []       # ordered unique graph.Param list
         self.nstreams = 1
         self.gemm_precision = 'f32'   # 'bf16x3': eligible convs run split-bf16 on the bf16 matrix cores (executor)
+        self.split_adds = True        # rule R9 / second-add rule applied (Planner: DEEPHAR_SPLIT_ADDS, read once)
 
     def total_flops(self, n=1):
         return sum(s.flops(n) for s in self.steps)
@@ -141,9 +142,14 @@ class Planner:
         self.g_inputs = inputs
         self.g_outputs = outputs
         self.nodes = G.topo_nodes(outputs)
-        if os.environ.get('DEEPHAR_SPLIT_ADDS', '1') != '0':      # (the switch exists for A/B measurements of rule R9)
+        # R9 and the second-add rule re-associate fp32 sums (conv + a + b for the reference's a + b + conv), so the switch
+        # -- it exists for A/B measurements -- is read ONCE per plan and recorded in it: a plan is built
+        # entirely under one setting, and Plan.split_adds says which.
+        self.split_adds = os.environ.get('DEEPHAR_SPLIT_ADDS', '1') != '0'
+        if self.split_adds:
             self.nodes = self._split_wide_adds(self.nodes, outputs)
         self.plan = Plan()
+        self.plan.split_adds = self.split_adds
         self.val = {}          # tensor uid -> Value | _Lazy
         self.absorbed = set()  # node uids folded into another step
         self.consumers = {}
@@ -442,7 +448,7 @@ class Planner:
                     epi['res2_down'] = True
                     self.absorbed.update((a2.uid, up.uid))
                     t = a2.outputs[0]
-            if epi['res1'] is not None and epi['res2'] is None and os.environ.get('DEEPHAR_SPLIT_ADDS', '1') != '0':
+            if epi['res1'] is not None and epi['res2'] is None and self.split_adds:
                 # a second two-operand add behind the first (SPNet: add([residual_unit(x), lateral]), spnet.py:303 on top of
                 # common.py:67): the free residual slot takes it -- (conv + shortcut) + lateral, the reference's order
                 n2 = self.sole_consumer(t, 'add')

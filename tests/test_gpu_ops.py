@@ -393,6 +393,25 @@ def test_pose3d_pieces(hip_lib, cuda):
     _close(vz, torch.amax(h5.mean(dim=(1, 2)), dim=1), atol=2e-6, what='vz')
 
 
+@pytest.mark.parametrize('hw,D,J', [((32, 32), 16, 17), ((32, 32), 8, 20), ((30, 30), 16, 17), ((7, 9), 4, 5)])
+def test_depth_means_paths_share_one_summation_order(hip_lib, cuda, hw, D, J):
+    """reception.py:193-222: both volume means.  The one-pass kernel (>= 96 frames) and the two small-batch kernels sum
+    in the same stated order: a frame's result does not depend on the batch it is in (bitwise), and both sit within a few
+    ulp of the fp64 mean (the round-4 one-pass kernel ran 256 serial additions per accumulator)."""
+    from deephar_amd import functional as F
+    rng = np.random.default_rng(120 + D + J)
+    h = _rand(rng, (4,) + hw + (D * J,), 30.0) + 100.0           # large common offset: rounding of long sums shows
+    t = torch.from_numpy(h)
+    small = [a.cpu() for a in F.depth_means(t.to(cuda), D, J)]
+    big = [a.cpu() for a in F.depth_means(t.repeat(32, 1, 1, 1).to(cuda), D, J)]     # 128 frames: one-pass kernel
+    for a, b, what in zip(small, big, ('hxy', 'hz')):
+        for r in range(32):
+            assert torch.equal(a, b[4 * r:4 * r + 4]), what
+    h5 = t.double().reshape(4, hw[0], hw[1], D, J)
+    assert (small[0].double() - h5.mean(dim=3)).abs().max().item() <= 4 * 130 * 2.0 ** -24
+    assert (small[1].double() - h5.mean(dim=(1, 2))).abs().max().item() <= 3 * 130 * 2.0 ** -24    # numpy emulation: 1.4 (new order), 5.5 (round-4 order)
+
+
 def test_kronecker_and_action_top(hip_lib, cuda):
     from deephar_amd import functional as F
     rng = np.random.default_rng(13)

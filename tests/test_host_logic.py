@@ -167,6 +167,7 @@ def test_planner_wide_adds_become_conv_epilogues(monkeypatch):
     monkeypatch.setenv('DEEPHAR_SPLIT_ADDS', '1')
     m1 = build()
     plan = m1.plan
+    assert base.split_adds is False and plan.split_adds is True      # read once per plan, recorded in it
     adds = lambda p: [s for s in p.steps if s.kind == 'eltwise' and s.attrs.get('op', 0) == 0 and 'b' in s.ins]
     assert len(adds(base)) == 15 and len(adds(plan)) == 0 and len(plan.steps) == len(base.steps) - 15
     assert sum(1 for n in m1._nodes if n.op == 'add' and len(n.inputs) == 4) == 5          # the graph itself keeps its adds (the last block re-injects nothing)
