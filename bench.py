@@ -13,6 +13,11 @@ Workloads (BASELINE.json `configs`):
               per GPU, frames shard like mpii.
   penn_merge  (configs[3]) merge model, 16-frame clips, 4 blocks, 15 actions, 4 clips per GPU and step;
   ntu_spnet   (configs[4]) SPNet pa17j3d, 60 actions, 32-frame clips, 8 clips per GPU and step.
+  speed2d     the reference's OWN speed protocol (exp/pennaction/eval_speed2d.py:31-79): SPNet-Penn, 6 pyramids, actions on
+              all six, pose_replica=True, 8-frame clips; for every prediction block b the truncated
+              Model(full.input, full.outputs[2b:2b+2]), one warm-up predict, then 250 clips through
+              predict(x, batch_size=2) on HOST arrays, wall clock -> `speed2d.fps_per_block` (18 entries).  A step of the
+              contract line (`value`) is one device-resident forward of the LAST block's model on 2 clips = 16 frames.
               Clip workloads are FRAME-SHARDED: every rank runs T/N frames of all N x clips_per_gpu clips through the
               frame stage (conv stack + decoder + kronecker pooling), ONE RCCL all-gather of the packed
               [clips, T/N, J, C] tensor, then the (tiny) action head replicated on every rank -- all device resident
@@ -104,6 +109,28 @@ def build_ntu_spnet():
     return m
 
 
+SPEED2D_CFG = dict(num_frames=8, num_joints=16, dim=2, num_actions=[15], num_pyramids=6,
+                   action_pyramids=[1, 2, 3, 4, 5, 6], num_levels=4, kernel_size=(5, 5), growth=96, image_div=8,
+                   num_pose_features=160, num_visual_features=160, sam_alpha=1, pose_replica=True)
+
+
+def build_speed2d():
+    """exp/pennaction/eval_speed2d.py:31-36,50: ModelConfig((8,) + (256, 256, 3), pa16j2d, num_actions=[15], num_pyramids=6,
+    action_pyramids=[1..6], num_levels=4, pose_replica=True, num_pose_features=160, num_visual_features=160)."""
+    from deephar_amd import graph, weights, utils
+    from deephar_amd.config import ModelConfig
+    from deephar_amd.models import spnet
+    graph.reset_naming()
+    c = SPEED2D_CFG
+    cfg = ModelConfig((c['num_frames'], 256, 256, 3), utils.pa16j2d, num_actions=c['num_actions'],
+                      num_pyramids=c['num_pyramids'], action_pyramids=c['action_pyramids'], num_levels=c['num_levels'],
+                      pose_replica=c['pose_replica'], num_pose_features=c['num_pose_features'],
+                      num_visual_features=c['num_visual_features'])
+    m = spnet.build(cfg)
+    weights.init_synthetic(m, seed=0)
+    return m
+
+
 WORKLOADS = {
     'mpii': dict(build=build_mpii, clips=False, per_gpu=64, T=1,
                  name='MPII single-person 256x256, ReceptionNet 8 blocks J=16 ctx=2 k=5, pose-only forward, batch=64 '
@@ -117,6 +144,10 @@ WORKLOADS = {
     'ntu_spnet': dict(build=build_ntu_spnet, clips=True, per_gpu=8, T=32,
                       name='NTU multitask SPNet, 32-frame 256x256 clips, 8 clips per GPU, frame-shard + RCCL all-gather '
                            '(BASELINE.json configs[4])'),
+    'speed2d': dict(build=build_speed2d, clips=False, per_gpu=2, T=8,
+                    name='exp/pennaction/eval_speed2d.py protocol: SPNet-Penn 2-D pose + action, 6 pyramids, actions on all, '
+                         'pose_replica, 8-frame 256x256 clips, truncated model of the LAST prediction block, 2 clips = 16 '
+                         'frames per step (the small-batch / latency regime)'),
 }
 
 
@@ -162,6 +193,14 @@ def cpu_baseline(model, workload, blocks):
         x = rng.uniform(-1, 1, (1, 16, 256, 256, 3)).astype(np.float32)
         run = lambda: oact.forward_merge(wd, x, 15, 16, 4, pose_dim=2, pose_net_version='v1', output_poses=True)
         what, src = 'one 16-frame clip', 'oracle/action.py'
+    elif workload == 'speed2d':
+        from oracle import spnet as osp
+        wd = weights.as_dict(model)
+        frames = 16
+        x = rng.uniform(-1, 1, (2, 8, 256, 256, 3)).astype(np.float32)
+        ocfg = {k: v for k, v in SPEED2D_CFG.items() if k != 'num_frames'}
+        run = lambda: osp.forward(wd, x, ocfg)
+        what, src = 'one batch of two 8-frame clips (every prediction block: the last block\'s model needs them all)', 'oracle/spnet.py'
     else:
         from oracle import spnet as osp
         wd = weights.as_dict(model)
@@ -348,6 +387,48 @@ def predict_boundary(model, batch, frames=2048):
     return res
 
 
+def speed2d_protocol(full_model, args, tune_table):
+    """exp/pennaction/eval_speed2d.py:60-79 on the HIP engine: for every prediction block b the truncated
+    Model(full.input, full.outputs[2b:2b+2]); `_ = m.predict(x[0:1])`; then wall clock around
+    `m.predict(x, batch_size=2)` over num_clips = 250 clips of 8 frames on HOST arrays; fps = 250 * 8 / seconds.
+    This engine specialises a plan per batch size (arena, tilings, hipGraph), so the reference's one-clip warm-up leaves the
+    two-clip plan cold: `fps_per_block_protocol_exact` is the first timed call (it includes binding, tuning misses and graph
+    capture of the two-clip plan), `fps_per_block` the same call again (what every later call of a caller's loop sees).  The
+    tilings found for one truncated model are shared with the next (same layers, same shapes)."""
+    from deephar_amd import Model
+    clips, T = args.speed2d_clips, SPEED2D_CFG['num_frames']
+    rng = np.random.default_rng(7)
+    distinct = min(clips, 10)                   # 10 distinct clips, tiled: drawing 400 M random floats takes seconds
+    x = np.tile(rng.uniform(-1, 1, (distinct, T, 256, 256, 3)).astype(np.float32), (-(-clips // distinct), 1, 1, 1, 1))[:clips]
+    nb = len(full_model.outputs) // 2
+    cold, warm, launches, gflop = [], [], [], []
+    blocks = range(nb) if args.speed2d_blocks is None else [int(b) for b in args.speed2d_blocks.split(',')]
+    for b in blocks:
+        m = Model(full_model.input, full_model.outputs[2 * b:2 * b + 2])
+        if args.streams is not None:
+            m.num_streams = args.streams
+        m.executor.tune_table = tune_table
+        m.executor.use_graph = not args.no_graph
+        m.predict(x[0:1])                                           # "Warming up the new model."
+        t0 = time.perf_counter()
+        out = m.predict(x, batch_size=2)
+        cold.append(round(clips * T / (time.perf_counter() - t0), 1))
+        t0 = time.perf_counter()
+        out = m.predict(x, batch_size=2)
+        warm.append(round(clips * T / (time.perf_counter() - t0), 1))
+        assert len(out) == 2 and len(out[0]) == clips and all(np.all(np.isfinite(o)) for o in out)
+        launches.append(len(m.plan.steps))
+        gflop.append(round(m.plan.total_flops(2) / 1e9, 2))
+        del m
+    return {'protocol': 'exp/pennaction/eval_speed2d.py:55-79', 'num_clips': clips, 'num_frames': T, 'batch_size': 2,
+            'blocks': list(blocks), 'fps_per_block': warm, 'fps_per_block_protocol_exact': cold,
+            'launches_per_call': launches, 'gflop_per_call': gflop,
+            'whole_forward_frac_per_block': [round(g * 1e9 * f / (2 * T) / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4)
+                                             for g, f in zip(gflop, warm)],
+            'note': 'host float32 arrays in, host arrays out, wall clock incl. H2D / D2H; fps_per_block = second timed call '
+                    '(two-clip plan warm), fps_per_block_protocol_exact = first timed call after the one-clip warm-up'}
+
+
 def setup_clips(workload, model, per_gpu, world, rank, args, load_tune=None, save_tune=None):
     """Frame-sharded clip workload: frame stage on T/world frames of every clip -> ONE all-gather -> replicated head."""
     import torch
@@ -507,6 +588,8 @@ def main():
     ap.add_argument('--replay-cfg', type=int, default=None,
                     help='with --replay-step on a conv step: force this tiling for the replayed launches (bit-identical; '
                          'lets the PMC passes cover the tilings the autotuner alternates between from box to box)')
+    ap.add_argument('--speed2d-clips', type=int, default=250, help='speed2d: clips per timed predict (eval_speed2d.py:30)')
+    ap.add_argument('--speed2d-blocks', default=None, help='speed2d: comma list of prediction blocks to time (default: all 18)')
     ap.add_argument('--predict-frames', type=int, default=2048,
                     help='frames per Model.predict boundary measurement (SURVEY.md 8d: >= 2 000)')
     args = ap.parse_args()
@@ -540,7 +623,7 @@ def main():
     wl = WORKLOADS[args.workload]
     per_gpu = args.batch or wl['per_gpu']
     model = wl['build'](args.blocks) if args.workload == 'mpii' else wl['build']()
-    if args.workload == 'h36m':
+    if args.workload in ('h36m', 'speed2d'):
         args.no_bf16x3 = args.no_clip_leg = True
     if args.streams is not None:
         model.num_streams = args.streams
@@ -572,10 +655,11 @@ def main():
         bp = ex.bind(n, u8_norm=1 if u8 else None)
         if tune:
             save_tune([ex.tune_table])
+        ishape = (n,) + tuple(model.inputs[0].shape)       # [n, 256, 256, 3] frames, or [n, T, 256, 256, 3] clips (speed2d)
         if u8:
-            x = np.random.default_rng(1234 + rank).integers(0, 256, (n, 256, 256, 3), dtype=np.uint8)
+            x = np.random.default_rng(1234 + rank).integers(0, 256, ishape, dtype=np.uint8)
         else:
-            x = np.random.default_rng(1234 + rank).uniform(-1, 1, (n, 256, 256, 3)).astype(np.float32)
+            x = np.random.default_rng(1234 + rank).uniform(-1, 1, ishape).astype(np.float32)
         with torch.cuda.stream(ex.stream):
             ex.set_inputs(bp, [x])           # inputs resident in HBM before the timed region
             x_dev = torch.from_numpy(x).to(ex.device)
@@ -595,7 +679,19 @@ def main():
                     bp.tensor(plan.inputs[0]).copy_(x_dev)
 
         check = lambda: bp.tensor(plan.outputs[-2]).cpu().numpy()
-        return step, [(bp, ex.stream_ptr)], [ex.stream], world * n, plan.total_flops(n), check, restage
+        return step, [(bp, ex.stream_ptr)], [ex.stream], world * n * wl['T'], plan.total_flops(n), check, restage
+
+    full_model = None
+    if args.workload == 'speed2d':
+        # the model a step runs is the truncated model of the LAST prediction block (eval_speed2d.py:62-68, bidx = 17: the
+        # last two action outputs, which need every pose and action block before them)
+        from deephar_amd import Model
+        full_model = model
+        nb = len(full_model.outputs) // 2
+        model = Model(full_model.input, full_model.outputs[2 * (nb - 1):2 * nb])
+        if args.streams is not None:
+            model.num_streams = args.streams
+        args.no_bf16x3 = args.no_clip_leg = True
 
     if not wl['clips']:
         step, bound, streams, frames_per_step, flops_per_step, check, restage = setup_frames(model)
@@ -694,6 +790,8 @@ def main():
         out = {
             'metric': 'frames/sec whole-node, 256x256 MPII pose fwd' if args.workload == 'mpii' else
                       'frames/sec whole-node, 256x256 Human3.6M 3-D pose fwd' if args.workload == 'h36m' else
+                      'frames/sec, SPNet-Penn 2-D pose + action, 8-frame clips, 2 clips per call (eval_speed2d.py protocol, '
+                      'last prediction block)' if args.workload == 'speed2d' else
                       'frames/sec whole-node, 256x256 pose + action fwd (%s)' % args.workload,
             'value': round(frames_per_step * args.steps / dt, 1),
             'unit': 'frames/s',
@@ -728,8 +826,10 @@ def main():
             out['predict_note'] = 'Model.predict on host numpy arrays, %d frames in batches of %d, wall clock incl. ' \
                                   'H2D of the frames and D2H of all outputs, after one warm-up call' % (
                                       args.predict_frames, per_gpu)
+        if args.workload == 'speed2d' and world == 1 and not args.no_predict:
+            out['speed2d'] = speed2d_protocol(full_model, args, model.executor.tune_table)
         if world == 1 and not args.no_cpu_baseline:
-            out['cpu_baseline'] = cpu_baseline(model, args.workload, args.blocks)
+            out['cpu_baseline'] = cpu_baseline(full_model if full_model is not None else model, args.workload, args.blocks)
         if args.dump_steps:
             dump = [dict(kind=s.kind, name=s.name, kernel=kernel_name(s) if s.kind == 'conv' else s.kind,
                          ms=ms, gflop=s.flops(n) / 1e9, mbytes=s.bytes(n) / 1e6,

@@ -105,7 +105,7 @@ SWEEP_S = (0.02, 0.04, 0.08, 0.15)
 def test_spnet_margin_sweep(name, hip_lib, cuda):
     """How far the engine is from the 1e-3 px bar as the read-out sensitivity S = sum p |g - x| of the fitted heads grows
     (VERDICT r03 item 1b): the same fit at S_TARGET in {0.02, 0.04, 0.08, 0.15}, one clip, fp32 mode.  RECORDED in
-    gpurun_out/parity_r04.json (`margin_sweep`: S asked / measured, worst |hip - o64|, |o32 - o64|, |hip - o32| over every
+    gpurun_out/parity_r05.json (`margin_sweep`: S asked / measured, worst |hip - o64|, |o32 - o64|, |hip - o32| over every
     prediction block); ASSERTED only where the fit reached its target and S <= wellcond.S_MAX = 0.05, the conditioning the
     flat test itself requires (S = 0.02 is not reachable on these maps: a peak between two cells keeps S at half a cell)."""
     from deephar_amd.models import spnet
