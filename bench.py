@@ -301,27 +301,28 @@ def roofline(rows, kinds, total_flops_per_step, ms_per_step):
     conv = dict(ms=sum(kinds[k]['ms'] for k in conv_kinds), flops=sum(kinds[k]['flops'] for k in conv_kinds),
                 launches=sum(kinds[k]['launches'] for k in conv_kinds))
     eager_total_ms = sum(ms for _, ms, _ in rows)
-    by_kernel = {}
+    # [r05] The line is keyed on the dominant LAUNCH SHAPE -- M x K x N plus epilogue, the unit SURVEY 8d prices -- not on a
+    # template instantiation: an instantiation also runs other shapes (round 4's `frac` averaged one over 18 launches of
+    # mixed shapes and could not be looked up in profiles/), and which of the near-equal tilings runs the dominant shape
+    # differs from box to box.  `kernel` = the instantiation(s) that ran that shape here; `traffic` = the PMC passes of
+    # tools/profile_round.py over the same shape + epilogue on the same instantiation (every tiling the autotuner
+    # alternates between is profiled), null only when none matches.
+    by_shape = {}
     for idx, (s, ms, n) in enumerate(rows):
         if s.kind != 'conv':
             continue
-        g = by_kernel.setdefault(kernel_name(s), dict(ms=0.0, flops=0.0, launches=0, shapes={}))
-        g['ms'] += ms
-        g['flops'] += s.flops(n)
-        g['launches'] += 1
         x, y = s.ins['x'], s.outs['y']
         key = (n * x.lead(3) * y.shape[-3] * y.shape[-2] // (4 if s.attrs['up2'] else 1), s.attrs['K'], s.attrs['Cout'],
                epilogue_tag(s))
-        sh = g['shapes'].setdefault(key, dict(ms=0.0, launches=0, flops=s.flops(n), bytes=s.bytes(n), step=idx))
+        sh = by_shape.setdefault(key, dict(ms=0.0, launches=0, flops=0.0, bytes=s.bytes(n), step=idx, kernels={}))
         sh['ms'] += ms
+        sh['flops'] += s.flops(n)
         sh['launches'] += 1
-    dom_name, dom = max(by_kernel.items(), key=lambda kv: kv[1]['ms'])
-    achieved = dom['flops'] / (dom['ms'] * 1e-3) / 1e12
-    # the shape this instantiation spends most of its time on: its algorithmic bytes (operands read once, result
-    # written once: Step.bytes) and, when the PMC passes of the same instantiation + shape exist, its HBM traffic
-    (m_, k_, n_, epi_), main = max(dom['shapes'].items(), key=lambda kv: kv[1]['ms'])
-    # `traffic` describes THE SAME launch as `algorithmic_bytes_per_launch`: same instantiation, same M x K x N and the
-    # same epilogue (BN / residuals / half-resolution residual), looked up in the PMC passes of tools/profile_round.py
+        kn = kernel_name(s)
+        sh['kernels'][kn] = sh['kernels'].get(kn, 0) + 1
+    (m_, k_, n_, epi_), main = max(by_shape.items(), key=lambda kv: kv[1]['ms'])
+    dom_name = max(main['kernels'].items(), key=lambda kv: kv[1])[0]
+    achieved = main['flops'] / (main['ms'] * 1e-3) / 1e12
     traffic, traffic_src, pmc_extra = None, None, {}
     pmc_path = os.path.join(ROOT, 'profiles', 'pmc_dominant_kernel.json')
     if os.path.exists(pmc_path):
@@ -336,18 +337,20 @@ def roofline(rows, kinds, total_flops_per_step, ms_per_step):
                 if 'mfma_busy_fraction' in ent:
                     pmc_extra['pmc_mfma_busy_fraction'] = ent['mfma_busy_fraction']
                 break
-    out = {'bound': 'mfma', 'kernel': dom_name,
+    out = {'bound': 'mfma', 'kernel': dom_name, 'kernels_on_main_shape': main['kernels'],
            'achieved': round(achieved, 2), 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
            'frac': round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), 'traffic': traffic,
            'traffic_unit': 'bytes/launch (HBM read + write, PMC) of the main shape', 'traffic_source': traffic_src,
+           'keyed_on': 'the launch shape (M x K x N + epilogue) with the largest summed time; achieved = its algorithmic '
+                       'FLOPs / its average launch duration (HIP events, eager pass)',
            'main_shape_mkn': [m_, k_, n_], 'main_shape_epilogue': epi_, 'main_shape_step_index': main['step'],
            'main_shape_launches_per_step': main['launches'],
            'main_shape_avg_launch_us': round(1e3 * main['ms'] / main['launches'], 2),
-           'algorithmic_bytes_per_launch': main['bytes'], 'algorithmic_gflop_per_launch': round(main['flops'] / 1e9, 3),
-           'launches_per_step': dom['launches'],
-           'avg_launch_us': round(1e3 * dom['ms'] / dom['launches'], 2),
-           'gflop_per_launch': round(dom['flops'] / dom['launches'] / 1e9, 2),
-           'share_of_step_time': round(dom['ms'] / eager_total_ms, 4),
+           'avg_launch_us': round(1e3 * main['ms'] / main['launches'], 2),
+           'algorithmic_bytes_per_launch': main['bytes'],
+           'algorithmic_gflop_per_launch': round(main['flops'] / main['launches'] / 1e9, 3),
+           'launches_per_step': main['launches'],
+           'share_of_step_time': round(main['ms'] / eager_total_ms, 4),
            'all_mfma_conv_kernels': {'launches_per_step': conv['launches'],
                                      'achieved': round(conv['flops'] / (conv['ms'] * 1e-3) / 1e12, 2),
                                      'frac': round(conv['flops'] / (conv['ms'] * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4),

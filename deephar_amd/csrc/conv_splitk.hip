@@ -1,24 +1,35 @@
-// Convolutions with a tiny output and a long reduction (the action heads: 3x3 over a [frames x joints] "image" with
-// hundreds of channels, 64-1024 output pixels; reference deephar/models/action.py / blocks.py): the MFMA kernels of
-// conv_igemm.hip / gemm1x1.hip give one 32 x 32 output tile to one wave, which then walks all of K alone -- 72 K-steps
-// of DMA round trip + 16 MFMAs each, 42-68 us for 0.0-0.3 GFLOP, on 2-64 of the chip's 1024 SIMDs.
-// Here a work-group of eight waves owns the 32 x 32 tile and splits K: wave w takes k-group pairs w, w + 8, ...; every
-// lane loads its own operands straight from global memory (A: four consecutive channels of its pixel's tap, B: the
-// packed weights' 16-byte unit of its column), eight pairs in flight, no LDS and no barrier in the loop; the eight
-// partial tiles are summed through LDS in wave order, then BN / residuals / ReLU.
-// The K order differs from the other conv kernels (eight interleaved partial sums), so this kernel is picked by a
-// SHAPE rule (conv_is_skinny: per-frame geometry only), never by timing, batch size or alignment: a layer always
-// computes the same bits.
+// Convolutions with a tiny output map (the action heads: 3x1 .. 3x5 and 1x1 convolutions over a [frames x joints] "image"
+// of 16-256 positions per clip, reference deephar/models/spnet.py:51-148, action.py:20-42; the heat-map heads of the
+// coarse SPNet levels, spnet.py:24-48): the MFMA kernels of conv_igemm.hip / gemm1x1.hip give one 32 x 32 output tile
+// to one wave, which then walks all of K alone.  v_mfma_f32_32x32x2_f32 issues once per 64 cycles, so a K = 480
+// reduction is a serial chain of 240 MFMAs = 6.4 us on ONE of the chip's 1024 SIMDs, whatever the memory system does;
+// at two 8-frame clips per call (exp/pennaction/eval_speed2d.py) 400 of the 621 launches of the last prediction
+// block's model are of this kind and ran 15-33 us each (profiles/r05_speed2d_first.json).
+//
+// Here a work-group of 4 / 8 / 16 waves owns the 32 x 32 tile and splits K into contiguous runs of k-group pairs
+// (8 k each: lanes lh = 0 / 1 take the k-groups 2 kp / 2 kp + 1).  Per chunk of eight pairs a lane issues ALL its
+// loads back to back -- A: the four consecutive channels of its pixel's tap (one 16-byte load; four dwords when
+// Cin % 4 != 0), B: the packed weights' 16-byte unit of its column -- and only then touches them: one memory round
+// trip per chunk, not one per pair [r05: round 2's kernel applied the BatchNormalization prologue inside the load
+// helper, i.e. waited for every pair before issuing the next -- 27 us for K = 1440].  The prologue's per-channel
+// scale / shift sit in LDS (staged while the first chunk is in flight); (tap, channel) of a k-group comes from one
+// multiply-high, no integer divide.  The partial tiles are summed through LDS in wave order, then BN / residuals / ReLU.
+//
+// The K order differs from the other conv kernels (NWV partial sums over contiguous K runs), so this kernel is picked
+// by a SHAPE rule (conv_is_skinny: per-frame geometry only), never by timing, batch size or alignment, and the number
+// of waves follows from K alone: a layer always computes the same bits.
 #include "conv_common.h"
 
 namespace dh {
 namespace {
 
-constexpr int SK_WAVES = 8;
-constexpr int SK_DEPTH = 8;      // k-group pairs in flight per wave
+constexpr int SK_MAX_CIN = 4096; // prologue table in LDS: 2 x Cin floats
 
-__global__ __launch_bounds__(SK_WAVES * 64) void conv_splitk_kernel(const ConvArgs p, const int xvec, const int affvec) {
-  __shared__ float red[SK_WAVES][16][64];
+template <int NWV, bool VEC>
+__global__ __launch_bounds__(NWV * 64) void conv_skinny_kernel(const ConvArgs p, const unsigned magic_cin, const unsigned magic_kw) {
+  extern __shared__ __attribute__((aligned(16))) float sk_lds[];
+  float (*red)[16][64] = reinterpret_cast<float (*)[16][64]>(sk_lds);          // [NWV][16][64] partial tiles
+  float* pre_tab = sk_lds + NWV * 16 * 64;                                       // [2][Cin4]: scale, shift (BN prologue only)
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int li = lane & 31, lh = lane >> 5;
@@ -26,6 +37,9 @@ __global__ __launch_bounds__(SK_WAVES * 64) void conv_splitk_kernel(const ConvAr
   const int tiles_n = (p.Cout + 31) / 32;
   const int m0 = (blockIdx.x / tiles_n) * 32;
   const int n0 = (blockIdx.x % tiles_n) * 32;
+  const bool aff = p.pre_scale != nullptr;
+  const int cin4 = (p.Cin + 3) & ~3;
+  constexpr int SK_DEPTH = VEC ? 8 : 4;                   // k-group pairs in flight per wave (dword form: 4 loads per pair and half)
 
   // this lane's output pixel (A operand row) and its top-left input position
   int m = m0 + li;
@@ -36,79 +50,135 @@ __global__ __launch_bounds__(SK_WAVES * 64) void conv_splitk_kernel(const ConvAr
   const int ih0 = oh * p.SH - p.PT, iw0 = ow * p.SW - p.PL;
   const float* xf = p.x + (size_t)fr * p.H * p.W * p.ldx;
   const float* wcol = p.w + (size_t)(n0 + li) * 4;        // packed [Kp / 4][Np][4]: unit (k-group, column)
-  const bool aff = p.pre_scale != nullptr;
-  const int pairs = p.Kp / 8;                             // k-group pairs: lanes lh = 0 / 1 take groups 2 kp / 2 kp + 1
+  const int pairs = p.Kp / 8;
+  const int per_wave = (pairs + NWV - 1) / NWV;
+  const int kp_begin = wave * per_wave;
+  const int kp_end = kp_begin + per_wave < pairs ? kp_begin + per_wave : pairs;
 
   f32x16 acc;
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-  const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
 
-  auto load = [&](int kp, float4& a, float4& b) {
-    const int kg = 2 * kp + lh;
-    const int k0 = 4 * kg;
-    b = *reinterpret_cast<const float4*>(wcol + (size_t)kg * p.Np * 4);
-    const int tap = k0 / p.Cin;
-    const int c = k0 - tap * p.Cin;                       // Cin % 4 == 0: the four k of a group share a tap
-    const int kh = tap / p.KW, kw = tap - kh * p.KW;
+  // element k -> its address relative to xf, or -1 outside the image / past K (zero padding applies AFTER the prologue)
+  auto locate = [&](int k, int& c) -> int {
+    const int tap = (int)__umulhi((unsigned)k, magic_cin);            // k / Cin
+    c = k - tap * p.Cin;
+    const int kh = (int)(((unsigned)tap * magic_kw) >> 16);            // tap / KW
+    const int kw = tap - kh * p.KW;
     const int ih = ih0 + kh, iw = iw0 + kw;
-    const bool ok = k0 < p.K && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
-    a = zero;
-    if (ok) {
-      const float* src = xf + ((size_t)ih * p.W + iw) * p.ldx + c;
-      if (xvec) a = *reinterpret_cast<const float4*>(src);
-      else a = make_float4(src[0], src[1], src[2], src[3]);       // same values, same arithmetic: same bits
-      if (aff) {
-        float4 sc, sh;
-        if (affvec) {
-          sc = *reinterpret_cast<const float4*>(p.pre_scale + c);
-          sh = *reinterpret_cast<const float4*>(p.pre_shift + c);
-        } else {
-          sc = make_float4(p.pre_scale[c], p.pre_scale[c + 1], p.pre_scale[c + 2], p.pre_scale[c + 3]);
-          sh = make_float4(p.pre_shift[c], p.pre_shift[c + 1], p.pre_shift[c + 2], p.pre_shift[c + 3]);
-        }
-        a.x = a.x * sc.x + sh.x; a.y = a.y * sc.y + sh.y; a.z = a.z * sc.z + sh.z; a.w = a.w * sc.w + sh.w;
-      }
-      if (p.pre_relu) { a.x = fmaxf(a.x, 0.f); a.y = fmaxf(a.y, 0.f); a.z = fmaxf(a.z, 0.f); a.w = fmaxf(a.w, 0.f); }
-    }
+    const bool ok = k < p.K && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
+    return ok ? (ih * p.W + iw) * p.ldx + c : -1;
   };
 
-  float4 fa[SK_DEPTH], fb[SK_DEPTH];
-#pragma unroll
-  for (int d = 0; d < SK_DEPTH; ++d) {
-    const int kp = wave + d * SK_WAVES;
-    fa[d] = zero; fb[d] = zero;
-    if (kp < pairs) load(kp, fa[d], fb[d]);
-  }
-  for (int kp = wave; kp < pairs; kp += SK_DEPTH * SK_WAVES) {
+  bool tab_ready = !aff;
+  for (int kp0 = kp_begin; kp0 < kp_end || !tab_ready; kp0 += SK_DEPTH) {
+    float4 fa[SK_DEPTH], fb[SK_DEPTH];
+    int ch[SK_DEPTH];              // VEC: channel of the group's first element (table index); scalar: k of the first element
+    unsigned okm = 0;              // VEC: bit d = pair d inside the image; scalar: 4 bits per pair
 #pragma unroll
     for (int d = 0; d < SK_DEPTH; ++d) {
-      const float4 a = fa[d], b = fb[d];
-      const int nxt = kp + (d + SK_DEPTH) * SK_WAVES;
-      fa[d] = zero; fb[d] = zero;
-      if (nxt < pairs) load(nxt, fa[d], fb[d]);           // lands while the other pairs are multiplied
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc, 0, 0, 0);     // a pair beyond `pairs` is zeros
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b.z, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b.w, acc, 0, 0, 0);
+      const int kp = kp0 + d;
+      const bool live = kp < kp_end;
+      const int kg = 2 * (live ? kp : 0) + lh;
+      fb[d] = *reinterpret_cast<const float4*>(wcol + (size_t)kg * p.Np * 4);
+      const int k0 = 4 * kg;
+      if constexpr (VEC) {
+        int c;
+        const int off = locate(k0, c);
+        const bool ok = live && off >= 0;
+        fa[d] = *reinterpret_cast<const float4*>(xf + (ok ? off : 0));
+        ch[d] = c;
+        okm |= (ok ? 1u : 0u) << d;
+      } else {
+        float e[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          int c;
+          const int off = locate(k0 + j, c);
+          const bool ok = live && off >= 0;
+          e[j] = xf[ok ? off : 0];
+          okm |= (ok ? 1u : 0u) << (4 * d + j);
+        }
+        fa[d] = make_float4(e[0], e[1], e[2], e[3]);
+        ch[d] = k0;
+      }
+    }
+    if (!tab_ready) {                                       // first pass: the table lands while the chunk is in flight
+      for (int i = tid; i < cin4; i += NWV * 64) {
+        pre_tab[i] = i < p.Cin ? p.pre_scale[i] : 0.f;
+        pre_tab[cin4 + i] = i < p.Cin ? p.pre_shift[i] : 0.f;
+      }
+      __syncthreads();
+      tab_ready = true;
+    }
+#pragma unroll
+    for (int d = 0; d < SK_DEPTH; ++d) {
+      float a[4] = {fa[d].x, fa[d].y, fa[d].z, fa[d].w};
+      if constexpr (VEC) {
+        if (aff) {
+          const float4 sc = *reinterpret_cast<const float4*>(pre_tab + ch[d]);
+          const float4 sh = *reinterpret_cast<const float4*>(pre_tab + cin4 + ch[d]);
+          a[0] = fmaf(a[0], sc.x, sh.x); a[1] = fmaf(a[1], sc.y, sh.y); a[2] = fmaf(a[2], sc.z, sh.z); a[3] = fmaf(a[3], sc.w, sh.w);
+        }
+        const bool ok = (okm >> d) & 1u;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          if (p.pre_relu) a[j] = fmaxf(a[j], 0.f);
+          a[j] = ok ? a[j] : 0.f;
+        }
+      } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          if (aff) {
+            const int k = ch[d] + j;
+            const int c = k - (int)__umulhi((unsigned)k, magic_cin) * p.Cin;
+            a[j] = fmaf(a[j], pre_tab[c], pre_tab[cin4 + c]);
+          }
+          if (p.pre_relu) a[j] = fmaxf(a[j], 0.f);
+          a[j] = ((okm >> (4 * d + j)) & 1u) ? a[j] : 0.f;
+        }
+      }
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[0], fb[d].x, acc, 0, 0, 0);     // a dead pair is zeros on the A side
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[1], fb[d].y, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[2], fb[d].z, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[3], fb[d].w, acc, 0, 0, 0);
     }
   }
 
+  // C layout of the 32x32 tile: register r of lane (li, lh) = row (r & 3) + 8 (r >> 2) + 4 lh, column li.  Thread t sums and
+  // writes the outputs t, t + NWV * 64, ...; their BN / residual values are fetched BEFORE the partial tiles go through
+  // LDS, so the epilogue's global round trip runs under the reduction instead of behind it.
+  constexpr int NOUT = (16 * 64) / (NWV * 64);
+  const int ohw = p.OH * p.OW;
+  float psc[NOUT], psh[NOUT], r1v[NOUT], r2v[NOUT];
+#pragma unroll
+  for (int i = 0; i < NOUT; ++i) {
+    const int idx = tid + i * NWV * 64;
+    const int r = idx >> 6, l = idx & 63;
+    const int row = (r & 3) + 8 * (r >> 2) + 4 * (l >> 5), col = l & 31;
+    const int mm = m0 + row, n = n0 + col;
+    const bool ok = mm < M && n < p.Cout;
+    const int mc = ok ? mm : 0, nc = ok ? n : 0;
+    psc[i] = p.post_scale != nullptr ? p.post_scale[nc] : 1.f;
+    psh[i] = p.post_scale != nullptr ? p.post_shift[nc] : 0.f;
+    r1v[i] = p.res1 != nullptr ? p.res1[(size_t)mc * p.ldr1 + nc] : 0.f;
+    r2v[i] = (p.res2 != nullptr && !p.up2) ? p.res2[(size_t)mc * p.ldr2 + nc] : 0.f;
+  }
 #pragma unroll
   for (int r = 0; r < 16; ++r) red[wave][r][lane] = acc[r];
   __syncthreads();
-  // C layout of the 32x32 tile: register r of lane (li, lh) = row (r & 3) + 8 (r >> 2) + 4 lh, column li
-  const int ohw = p.OH * p.OW;
-  for (int idx = tid; idx < 16 * 64; idx += SK_WAVES * 64) {
+#pragma unroll
+  for (int i = 0; i < NOUT; ++i) {
+    const int idx = tid + i * NWV * 64;
     const int r = idx >> 6, l = idx & 63;
     const int row = (r & 3) + 8 * (r >> 2) + 4 * (l >> 5), col = l & 31;
     const int mm = m0 + row, n = n0 + col;
     if (mm >= M || n >= p.Cout) continue;
     float t = red[0][r][l];
 #pragma unroll
-    for (int w = 1; w < SK_WAVES; ++w) t += red[w][r][l];
-    if (p.post_scale != nullptr) t = t * p.post_scale[n] + p.post_shift[n];
-    if (p.res1 != nullptr) t += p.res1[(size_t)mm * p.ldr1 + n];
+    for (int w = 1; w < NWV; ++w) t += red[w][r][l];
+    if (p.post_scale != nullptr) t = t * psc[i] + psh[i];
+    if (p.res1 != nullptr) t += r1v[i];
     if (p.up2) {
       const int f2 = mm / ohw;
       const int rm = mm - f2 * ohw;
@@ -122,32 +192,62 @@ __global__ __launch_bounds__(SK_WAVES * 64) void conv_splitk_kernel(const ConvAr
         p.y[mo * p.ldy + n] = o;
       }
     } else {
-      if (p.res2 != nullptr) t += p.res2[(size_t)mm * p.ldr2 + n];
+      if (p.res2 != nullptr) t += r2v[i];
       if (p.post_relu) t = fmaxf(t, 0.f);
       p.y[(size_t)mm * p.ldy + n] = t;
     }
   }
 }
 
+template <int NWV>
+int launch_skinny(const ConvArgs& a, unsigned tiles, bool vec, hipStream_t s) {
+  const unsigned magic_cin = (unsigned)((1ull << 32) / (unsigned)a.Cin + 1ull);       // k / Cin = umulhi(k, magic), k * Cin < 2^32
+  const unsigned magic_kw = (1u << 16) / (unsigned)a.KW + 1u;                          // tap / KW for tap < 2^8
+  const size_t lds = ((size_t)NWV * 16 * 64 + (a.pre_scale != nullptr ? (size_t)2 * ((a.Cin + 3) & ~3) : 0)) * sizeof(float);
+  constexpr int lds_max = (NWV * 16 * 64 + 2 * SK_MAX_CIN) * (int)sizeof(float);     // <= 96 KB of the CU's 160
+  if (vec) {
+    static LdsLimit lim;
+    if (lds_max > 64 * 1024) lim.raise((const void*)conv_skinny_kernel<NWV, true>, lds_max);
+    hipLaunchKernelGGL((conv_skinny_kernel<NWV, true>), dim3(tiles), dim3(NWV * 64), lds, s, a, magic_cin, magic_kw);
+  } else {
+    static LdsLimit lim;
+    if (lds_max > 64 * 1024) lim.raise((const void*)conv_skinny_kernel<NWV, false>, lds_max);
+    hipLaunchKernelGGL((conv_skinny_kernel<NWV, false>), dim3(tiles), dim3(NWV * 64), lds, s, a, magic_cin, magic_kw);
+  }
+  return check_launch();
+}
+
 }  // namespace
 
 // Shape rule -- deterministic, independent of timing, of the batch size and of buffer alignment (the bits of a layer
-// must not depend on any of them): at most 256 output pixels per frame / clip, a reduction of at least 768, at most 256
-// output channels, channels in groups of four.
+// must not depend on any of them): at most 256 output positions per frame / clip, at most 256 output channels, a
+// reduction of at least 64 (shorter ones are one or two K-steps of the general kernel anyway).  [r05: was K >= 768 and
+// Cin % 4 == 0 -- the action heads' 1x1 / 3x3 convolutions with K = 70 .. 720 ran 15-33 us on one wave per tile.]
 bool conv_is_skinny(const ConvArgs& a) {
   if (a.x_u8 || a.w_split) return false;
-  return a.OH * a.OW <= 256 && a.K >= 768 && a.Cout <= 256 && a.Cin % 4 == 0;
+  return a.OH * a.OW <= 256 && a.K >= 64 && a.Cout <= 256 && a.Cin >= 2 && a.Cin <= SK_MAX_CIN && a.KW < 256 &&
+         (long long)a.K * a.Cin < (1ll << 31);
+}
+
+// waves per tile: from K alone (8 k per pair, eight pairs per wave and chunk)
+int conv_skinny_waves(int Kp) {
+  const int pairs = Kp / 8;
+  return pairs > 64 ? 16 : (pairs > 16 ? 8 : 4);
 }
 
 int launch_conv_splitk(const ConvArgs& a, hipStream_t s) {
   const long long M = (long long)a.N * a.OH * a.OW;
   const long long tiles = ((M + 31) / 32) * ((a.Cout + 31) / 32);
-  if (tiles <= 0 || tiles > 0x7fffffffLL) return DH_EINVAL;
+  if (tiles <= 0 || tiles > 0x7fffffffLL || (long long)a.H * a.W * a.ldx > 0x7fffffffLL) return DH_EINVAL;
   auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
-  const int xvec = a.ldx % 4 == 0 && al16(a.x);
-  const int affvec = a.pre_scale != nullptr && al16(a.pre_scale) && al16(a.pre_shift);
-  hipLaunchKernelGGL(conv_splitk_kernel, dim3((unsigned)tiles), dim3(SK_WAVES * 64), 0, s, a, xvec, affvec);
-  return check_launch();
+  // (the vector form is a property of the layer wherever the engine lays tensors out 16-byte aligned; both forms load
+  //  the same values and run the same arithmetic: same bits)
+  const bool vec = a.Cin % 4 == 0 && a.ldx % 4 == 0 && al16(a.x);
+  switch (conv_skinny_waves(a.Kp)) {
+    case 16: return launch_skinny<16>(a, (unsigned)tiles, vec, s);
+    case 8: return launch_skinny<8>(a, (unsigned)tiles, vec, s);
+    default: return launch_skinny<4>(a, (unsigned)tiles, vec, s);
+  }
 }
 
 }  // namespace dh

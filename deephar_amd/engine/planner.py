@@ -71,7 +71,7 @@ class Value:
 def split_k_rule(out_pixels, K, cout, cin):
     """Mirror of conv_is_skinny (csrc/conv_splitk.hip; dh_conv2d_uses_split_k): the layers dh_conv2d_f32 runs on its
     in-work-group split-K kernel -- per-frame geometry only, so a layer's bits depend on neither batch size nor tiling."""
-    return out_pixels <= 256 and K >= 768 and cout <= 256 and cin % 4 == 0
+    return out_pixels <= 256 and K >= 64 and cout <= 256 and 2 <= cin <= 4096
 
 
 class Step:

@@ -12,6 +12,9 @@ either as a shape mismatch here or as a numeric mismatch in tests/test_reference
     python tests/golden/make_reference_golden.py --smooth   ->  tests/golden/reference_models_smooth.npz
         (SPNet on the well-conditioned vectors of tests/wellcond.py: video clips + heat-map heads fitted on the
          oracle; the fitted head kernels are stored beside the outputs, '<tag>/head/<layer name>')
+    python tests/golden/make_reference_golden.py --real     ->  tests/golden/reference_models_real.npz
+        (the BASELINE configurations at their REAL size: ReceptionNet 8 blocks 2-D / 3-D at 256 px, the merge model of
+         eval_penn_ar_pe_merge.py at T = 16 / 4 blocks / 256 px, SPNet-NTU at T = 32 / 256 px with fitted heads)
 """
 import importlib
 import os
@@ -115,6 +118,8 @@ def draw(tag, shape):
 TAGS = ('rec2d', 'rec3d', 'merge2d', 'merge3d', 'spnet3d', 'spnet2d', 'spnet2dr')
 SMOOTH_TAGS = ('spnet3d_s', 'spnet2d_s', 'spnet2dr_s')
 OUT_SMOOTH = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'reference_models_smooth.npz')
+REAL_TAGS = ('rec2d_8', 'rec3d_8', 'merge2d_16', 'spnet3d_32_s')
+OUT_REAL = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'reference_models_real.npz')
 
 
 def build_pair(R, tag):
@@ -135,6 +140,25 @@ def build_pair(R, tag):
         ref = R['models.reception'].build((256, 256, 3), 17, dim=3, **kw)
         prod = prec.build((256, 256, 3), 17, dim=3, **kw)
         return ref, prod, draw(tag, (2, 256, 256, 3))
+    if tag == 'rec2d_8':    # configs[1] at its real depth (reception.py:277-312 loop indices 3 .. 8)
+        kw = dict(num_context_per_joint=2, num_blocks=8, ksize=(5, 5), concat_pose_confidence=False)
+        ref = R['models.reception'].build((256, 256, 3), 16, dim=2, **kw)
+        prod = prec.build((256, 256, 3), 16, dim=2, **kw)
+        return ref, prod, draw(tag, (2, 256, 256, 3))
+    if tag == 'rec3d_8':    # configs[2] at its real depth
+        kw = dict(num_blocks=8, depth_maps=16, ksize=(5, 5))
+        ref = R['models.reception'].build((256, 256, 3), 17, dim=3, **kw)
+        prod = prec.build((256, 256, 3), 17, dim=3, **kw)
+        return ref, prod, draw(tag, (2, 256, 256, 3))
+    if tag == 'merge2d_16':  # configs[3] exactly as exp/pennaction/eval_penn_ar_pe_merge.py:51-57 builds it (action.py:127-153 at 4 blocks)
+        pe_kw = dict(num_blocks=4, num_context_per_joint=2, ksize=(5, 5), concat_pose_confidence=False)
+        ref_pe = R['models.reception'].build((256, 256, 3), 16, dim=2, **pe_kw)
+        ref = R['models.action'].build_merge_model(ref_pe, 15, (256, 256, 3), 16, 16, 4, pose_dim=2,
+                                                   pose_net_version='v1', full_trainable=False)
+        prod_pe = prec.build((256, 256, 3), 16, dim=2, **pe_kw)
+        prod = pact.build_merge_model(prod_pe, 15, (256, 256, 3), 16, 16, 4, pose_dim=2, pose_net_version='v1',
+                                      full_trainable=False)
+        return ref, prod, draw(tag, (1, 16, 256, 256, 3))
     if tag in ('merge2d', 'merge3d'):   # merge action model, 2-D v1 (cfg 4 family) and 3-D v2
         dim, J, ver = (2, 16, 'v1') if tag == 'merge2d' else (3, 20, 'v2')
         T = 4
@@ -155,7 +179,9 @@ def build_pair(R, tag):
     smooth = tag.endswith('_s')
     T, lay, nact, pyr, apyr, feats, res, rep = {'spnet3d': (4, 'pa17j3d', 60, 2, [1, 2], 192, 128, False),
                                                 'spnet2d': (16, 'pa16j2d', 15, 2, [2], 160, 128, False),
-                                                'spnet2dr': (8, 'pa16j2d', 15, 6, [5, 6], 160, 128, True)}[
+                                                'spnet2dr': (8, 'pa16j2d', 15, 6, [5, 6], 160, 128, True),
+                                                # configs[4]: T = 32 -> time_stride 2 (spnet.py:100), 256 px
+                                                'spnet3d_32': (32, 'pa17j3d', 60, 2, [1, 2], 192, 256, False)}[
         tag[:-2] if smooth else tag]
     R['models.spnet'].__dict__.pop('act_cnt', None)       # the reference's process-global counter
     rcfg = R['config'].ModelConfig((T, res, res, 3), getattr(putils, lay), num_actions=[nact], num_pyramids=pyr,
@@ -223,16 +249,18 @@ def check_weight_files(tag, ref_model, product_model):
           ('by name' if by_name else 'by order', 'n/a (by-name family)' if by_name else 'by order'))
 
 
-def main(smooth=False):
+def main(smooth=False, real=False):
     import json
+    import time
     from deephar_amd import weights
     R = load_reference()
     g = {}
     layouts = {}
-    for tag in (SMOOTH_TAGS if smooth else TAGS):
+    for tag in (REAL_TAGS if real else SMOOTH_TAGS if smooth else TAGS):
+        t0 = time.time()
         ref_model, product_model, x = build_pair(R, tag)
         weights.init_synthetic(product_model, seed=0)
-        if smooth:
+        if tag.endswith('_s'):
             import refgolden
             import wellcond
             heads = wellcond.fit_spnet_heads(product_model, refgolden.spnet_ocfg(tag), x.astype(np.float32),
@@ -248,9 +276,9 @@ def main(smooth=False):
             for i, a in enumerate(arrs):
                 g['%s/%s/%d' % (tag, k, i)] = a.astype(np.float64 if k == 'f64' else np.float32)
         g['%s/nout' % tag] = np.array(len(outs['f64']))
-        print(tag, 'outputs', [a.shape for a in outs['f64']], 'weights set', n)
-    out = OUT_SMOOTH if smooth else OUT
-    if not smooth:
+        print(tag, 'outputs', [a.shape for a in outs['f64']], 'weights set', n, '%.0f s' % (time.time() - t0), flush=True)
+    out = OUT_REAL if real else OUT_SMOOTH if smooth else OUT
+    if not smooth and not real:
         with open(os.path.join(os.path.dirname(OUT), 'keras_layouts.json'), 'w') as fh:
             json.dump(layouts, fh, separators=(',', ':'))
     np.savez_compressed(out, **g)
@@ -258,4 +286,4 @@ def main(smooth=False):
 
 
 if __name__ == '__main__':
-    main(smooth='--smooth' in sys.argv)
+    main(smooth='--smooth' in sys.argv, real='--real' in sys.argv)

@@ -11,9 +11,15 @@ GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'ref
 # the '<tag>_s' cases: SPNet on well-conditioned vectors (tests/wellcond.py: video clips + fitted heat-map heads);
 # the fitted head kernels travel with the outputs, so a test rebuilds exactly the weights the reference code ran on
 GOLDEN_SMOOTH = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'reference_models_smooth.npz')
+# [r05] the '<tag>' cases of REAL_CASES: the BASELINE configurations at their real size (8 blocks at 256 px; the merge
+# model exactly as exp/pennaction/eval_penn_ar_pe_merge.py:51-57 builds it: T = 16, 4 blocks, nine action heads;
+# SPNet-NTU at T = 32 / 256 px, where spnet.py:100 switches time_stride to 2) -- outputs only
+GOLDEN_REAL = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'reference_models_real.npz')
 SPNET_CASES = {'spnet3d': (4, 'pa17j3d', 60, 2, [1, 2], 192, False),
                'spnet2d': (16, 'pa16j2d', 15, 2, [2], 160, False),
-               'spnet2dr': (8, 'pa16j2d', 15, 6, [5, 6], 160, True)}
+               'spnet2dr': (8, 'pa16j2d', 15, 6, [5, 6], 160, True),
+               'spnet3d_32': (32, 'pa17j3d', 60, 2, [1, 2], 192, False)}
+SPNET_RES = {'spnet3d_32': 256}          # input resolution (default 128)
 SMOOTH_SEED = 31
 
 
@@ -22,11 +28,12 @@ def case_input(tag, shape):
     return np.random.default_rng(seed).uniform(-1, 1, shape)
 
 
-def smooth_input(tag, res=128):
+def smooth_input(tag, res=None):
     """(clips float32 [1, T, res, res, 3], peak positions [T, J, 2]) of a '<tag>_s' case."""
     import wellcond
     from deephar_amd import utils
     T, lay = SPNET_CASES[tag[:-2]][:2]
+    res = res or SPNET_RES.get(tag[:-2], 128)
     J = getattr(utils, lay).num_joints
     seed = SMOOTH_SEED + sorted(SPNET_CASES).index(tag[:-2])
     return wellcond.video_clips(1, T, res, seed), wellcond.joint_positions(1, T, J, seed)
@@ -41,8 +48,12 @@ def spnet_ocfg(tag):
                 num_pose_features=feats, num_visual_features=feats, sam_alpha=1, pose_replica=rep)
 
 
+def golden_file(tag):
+    return GOLDEN_REAL if tag in REAL_CASES else GOLDEN_SMOOTH if tag.endswith('_s') else GOLDEN
+
+
 def golden(tag):
-    g = np.load(GOLDEN_SMOOTH if tag.endswith('_s') else GOLDEN)
+    g = np.load(golden_file(tag))
     n = int(g['%s/nout' % tag])
     return [g['%s/f32/%d' % (tag, i)] for i in range(n)], [g['%s/f64/%d' % (tag, i)] for i in range(n)]
 
@@ -65,6 +76,24 @@ def build_case(tag):
         m = reception.build((256, 256, 3), 17, dim=3, **kw)
         x = case_input(tag, (2, 256, 256, 3))
         run = lambda wd, dt: oref.forward(wd, x, 17, 3, dtype=dt, **kw)
+    elif tag == 'rec2d_8':      # configs[1]: 8 blocks, 2 contexts per joint (exp/mpii/eval_mpii_singleperson.py:46-50)
+        kw = dict(num_context_per_joint=2, num_blocks=8, ksize=(5, 5), concat_pose_confidence=False)
+        m = reception.build((256, 256, 3), 16, dim=2, **kw)
+        x = case_input(tag, (2, 256, 256, 3))
+        run = lambda wd, dt: oref.forward(wd, x, 16, 2, dtype=dt, **kw)
+    elif tag == 'rec3d_8':      # configs[2]: 8 blocks, J = 17, 16 depth maps (exp/h36m/eval_h36m.py:42-48)
+        kw = dict(num_blocks=8, depth_maps=16, ksize=(5, 5))
+        m = reception.build((256, 256, 3), 17, dim=3, **kw)
+        x = case_input(tag, (2, 256, 256, 3))
+        run = lambda wd, dt: oref.forward(wd, x, 17, 3, dtype=dt, **kw)
+    elif tag == 'merge2d_16':   # configs[3]: exp/pennaction/eval_penn_ar_pe_merge.py:51-57 (nine action heads, no poses)
+        pe = reception.build((256, 256, 3), 16, dim=2, num_blocks=4, num_context_per_joint=2, ksize=(5, 5),
+                             concat_pose_confidence=False)
+        m = action.build_merge_model(pe, 15, (256, 256, 3), 16, 16, 4, pose_dim=2, pose_net_version='v1',
+                                     full_trainable=False)
+        x = case_input(tag, (1, 16, 256, 256, 3))
+        okw = dict(pose_dim=2, pose_net_version='v1', output_poses=False, num_context_per_joint=2)
+        run = lambda wd, dt: oact.forward_merge(wd, x, 15, 16, 4, dtype=dt, **okw)
     elif tag in ('merge2d', 'merge3d'):
         dim, J, ver = (2, 16, 'v1') if tag == 'merge2d' else (3, 20, 'v2')
         pe_kw = dict(num_context_per_joint=2, num_blocks=2, ksize=(5, 5)) if dim == 2 else \
@@ -79,10 +108,11 @@ def build_case(tag):
     elif tag in SPNET_CASES or (tag.endswith('_s') and tag[:-2] in SPNET_CASES):
         T, lay, nact, pyr, apyr, feats, rep = SPNET_CASES[tag[:-2] if tag.endswith('_s') else tag]
         layout = getattr(utils, lay)
-        cfg = ModelConfig((T, 128, 128, 3), layout, num_actions=[nact], num_pyramids=pyr, action_pyramids=apyr,
+        res = SPNET_RES.get(tag[:-2] if tag.endswith('_s') else tag, 128)
+        cfg = ModelConfig((T, res, res, 3), layout, num_actions=[nact], num_pyramids=pyr, action_pyramids=apyr,
                           num_levels=4, pose_replica=rep, num_pose_features=feats, num_visual_features=feats)
         m = spnet.build(cfg)
-        x = smooth_input(tag)[0] if tag.endswith('_s') else case_input(tag, (1, T, 128, 128, 3))
+        x = smooth_input(tag)[0] if tag.endswith('_s') else case_input(tag, (1, T, res, res, 3))
         ocfg = spnet_ocfg(tag)
         run = lambda wd, dt, taps=None: osp.forward(wd, x, ocfg, dtype=dt, taps=taps)
     else:
@@ -90,7 +120,7 @@ def build_case(tag):
     weights.init_synthetic(m, seed=0)
     if tag.endswith('_s'):
         import wellcond
-        g = np.load(GOLDEN_SMOOTH)
+        g = np.load(golden_file(tag))
         pre = '%s/head/' % tag
         wellcond.apply_heads(m, {k[len(pre):]: g[k] for k in g.files if k.startswith(pre)})
     wd = weights.as_dict(m)
@@ -99,3 +129,4 @@ def build_case(tag):
 
 CASES = ['rec2d', 'rec3d', 'merge2d', 'merge3d', 'spnet3d', 'spnet2d', 'spnet2dr']
 SMOOTH_CASES = ['spnet3d_s', 'spnet2d_s', 'spnet2dr_s']
+REAL_CASES = ['rec2d_8', 'rec3d_8', 'merge2d_16', 'spnet3d_32_s']

@@ -409,6 +409,32 @@ def test_hip_matches_reference_code_goldens(tag, hip_lib, cuda):
             _check('%s.out%d' % (tag, k), h, a, b, PX_TOL if b.shape[-1] != 1 else 1e-5, rel=(b.shape[-1] == 1))
 
 
+@pytest.mark.parametrize('tag', ['rec2d_8', 'rec3d_8', 'merge2d_16'])
+def test_hip_matches_reference_code_goldens_at_real_size(tag, hip_lib, cuda):
+    """[r05] HIP engine vs golden vectors of the reference's OWN model code at the REAL size of BASELINE configs[1..3]
+    (tests/golden/make_reference_golden.py --real): 8-block ReceptionNet 2-D / 3-D at 256 px within a flat 1e-3 px of the
+    reference code's fp64 run; the merge model as exp/pennaction/eval_penn_ar_pe_merge.py:51-57 builds it (T = 16, 4 blocks):
+    identical arg-max labels on all nine heads.  No oracle in the loop: the golden IS the reference code's output.
+    (SPNet-NTU at T = 32: tests/test_gpu_spnet_flat.py, same file of goldens.)"""
+    import sys, os
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from refgolden import build_case, golden
+    m, x, _ = build_case(tag)
+    g32, g64 = golden(tag)
+    hip = m.predict(x.astype(np.float32), batch_size=len(x))
+    hip = hip if isinstance(hip, list) else [hip]
+    assert [h.shape for h in hip] == [g.shape for g in g64]
+    for k, (h, a, b) in enumerate(zip(hip, g32, g64)):
+        if tag == 'merge2d_16':
+            _check('%s.act%d' % (tag, k), h, a, b, 1e-5)
+            assert np.array_equal(h.argmax(-1), b.argmax(-1)), 'action label differs on head %d' % k
+        elif tag == 'rec3d_8':          # [N, 17, 4] = xyz + visibility (concat_pose_confidence=True)
+            _check('%s.xyz%d' % (tag, k), h[..., :3], a[..., :3], b[..., :3], PX_TOL)
+            _check('%s.vis%d' % (tag, k), h[..., 3:], a[..., 3:], b[..., 3:], 1e-6)
+        else:                           # pose [N, 16, 2], visibility [N, 16, 1] per block
+            _check('%s.out%d' % (tag, k), h, a, b, PX_TOL if b.shape[-1] != 1 else 1e-5, rel=(b.shape[-1] == 1))
+
+
 @pytest.mark.parametrize('tag', ['rec2d', 'merge2d', 'spnet2d'])
 def test_uint8_frames_equal_host_normalised_frames(tag, hip_lib, cuda):
     """Model.predict on raw uint8 frames (normalisation fused into the first convolution, 4x fewer input bytes)

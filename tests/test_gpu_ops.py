@@ -699,6 +699,14 @@ SKINNY_CASES = [
     (3, 32, 20, 192, 192, 3, 2, False, True, True),      # strided (out 16 x 10), residual
     (2, 4, 4, 256, 15, 3, 1, False, False, False),       # 16 output pixels per clip: half-empty row tile
     (5, 8, 8, 1024, 60, 1, 1, False, True, False),       # pointwise with a long K
+    # [r05] the rule reaches down to K = 64 and takes any Cin: the action heads of SPNet at T = 8 (spnet.py:51-148)
+    (2, 8, 16, 70, 160, 1, 1, True, True, False),        # K = 70: Cin % 4 != 0 -> dword loads, 4 waves, BN + ReLU prologue
+    (2, 8, 8, 15, 160, 3, 1, False, True, True),         # K = 135 = 3 x 3 x 15: k-groups straddle taps
+    (2, 8, 16, 80, 160, 3, 1, False, False, True),       # K = 720: 16 waves, one chunk each
+    (2, 8, 8, 480, 40, 1, 1, True, True, False),         # K = 480: 8 waves
+    (3, 16, 16, 384, 16, 1, 1, True, True, False),       # a heat-map head of the 16 x 16 level: Cout = 16
+    (2, 8, 8, 160, 160, 3, 1, True, True, False),        # K = 1440: two chunks per wave, prologue + zero padding
+    (1, 4, 4, 576, 16, 1, 1, True, True, False),         # 16 positions in all: half a row tile
 ]
 
 
@@ -760,8 +768,8 @@ def test_conv2d_split_k_kernel(case, hip_lib, cuda):
     assert hip_lib.dh_conv2d_f32(C.byref(a), -1, torch.cuda.current_stream().cuda_stream) == 0
     torch.cuda.synchronize()
     assert torch.equal(y, got)
-    a.K = 288; a.Cin = 288; a.KH = a.KW = 1                                   # an MPII 16 x 16 pointwise conv: not skinny
-    assert hip_lib.dh_conv2d_uses_split_k(C.byref(a)) == 0
+    a.K = 288; a.Cin = 288; a.Cout = 288; a.KH = a.KW = 1                     # an MPII 16 x 16 pointwise conv: not skinny
+    assert hip_lib.dh_conv2d_uses_split_k(C.byref(a)) == 0                   # (more than 256 output channels)
 
 
 @pytest.mark.parametrize('case', SPLIT_CASES)

@@ -136,7 +136,7 @@ def test_spnet_margin_sweep(name, hip_lib, cuda):
 
 
 @pytest.mark.parametrize('mode', ['f32', 'bf16x3'])
-@pytest.mark.parametrize('tag', ['spnet3d_s', 'spnet2d_s', 'spnet2dr_s'])
+@pytest.mark.parametrize('tag', ['spnet3d_s', 'spnet2d_s', 'spnet2dr_s', 'spnet3d_32_s'])
 def test_hip_matches_smooth_reference_code_goldens(tag, mode, hip_lib, cuda):
     """HIP engine vs golden vectors computed by the reference's OWN spnet.py / common.py / layers.py (on mini-Keras) for
     the well-conditioned vectors: flat 1e-3 px on every pose output, identical arg-max action labels."""

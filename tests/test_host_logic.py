@@ -188,7 +188,7 @@ def test_planner_wide_adds_become_conv_epilogues(monkeypatch):
 
 def test_planner_r3_spares_split_k_producers():
     """add([conv(x), UpSampling2D(b)]) must not become the half-resolution second residual (res2_down) of a
-    convolution that dh_conv2d_f32 runs on the split-K kernel (per-frame output <= 256 pixels, K >= 768, Cout <= 256:
+    convolution that dh_conv2d_f32 runs on the split-K kernel (per-frame output <= 256 pixels, K >= 64, Cout <= 256:
     conv_igemm.hip returns DH_EUNSUPPORTED for that pair) -- the plan falls back to an up-sampling kernel; a producer
     outside the rule still takes R3."""
     from deephar_amd import Model, graph
@@ -208,8 +208,8 @@ def test_planner_r3_spares_split_k_producers():
     convs = {s.name: s for s in skinny.steps if s.kind == 'conv'}
     assert not convs['a'].attrs['res2_down'] and 'res2' not in convs['a'].ins
     assert any(s.kind == 'upsample_add' for s in skinny.steps) or any(s.attrs.get('up2') for s in convs.values())
-    assert not split_k_rule(16 * 16, 512, 128, 512)
-    wide = build(512, 128, 16)
+    assert not split_k_rule(16 * 16, 512, 288, 512)
+    wide = build(512, 288, 16)
     convs = {s.name: s for s in wide.steps if s.kind == 'conv'}
     assert convs['a'].attrs['res2_down'] == 1 and not any(s.kind == 'upsample_add' for s in wide.steps)
     # sep-conv producer: the rule looks at its pointwise half (K = Cin)

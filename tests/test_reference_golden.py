@@ -8,7 +8,7 @@ import numpy as np
 import pytest
 import torch
 
-from refgolden import CASES, SMOOTH_CASES, build_case, golden
+from refgolden import CASES, REAL_CASES, SMOOTH_CASES, build_case, golden
 
 
 @pytest.mark.parametrize('tag', CASES + SMOOTH_CASES)
@@ -23,6 +23,22 @@ def test_oracle_matches_reference_code(tag):
     o32 = run(torch.float32)
     for k, (a, b) in enumerate(zip(o32, g32)):
         assert np.abs(a - b).max() <= 2e-5 * max(1.0, np.abs(b).max()), (tag, k, np.abs(a - b).max())
+
+
+@pytest.mark.parametrize('tag', REAL_CASES)
+def test_oracle_matches_reference_code_at_real_size(tag):
+    """[r05] The BASELINE configurations at their REAL size -- ReceptionNet 8 blocks 2-D (configs[1]) and 3-D (configs[2]) at
+    256 px, the merge model exactly as exp/pennaction/eval_penn_ar_pe_merge.py:51-57 builds it (T = 16, 4 blocks, nine
+    heads), SPNet-NTU at T = 32 / 256 px (time_stride 2, spnet.py:100) -- against the reference's own model code run on
+    mini-Keras: pins reception.py:277-312 at loop indices 3 .. 8 and action.py:127-153 at 4 blocks, which no reduced golden
+    reaches.  fp64 only (the fp32 leg of the small cases above already covers dtype handling; this keeps the CPU suite
+    within minutes)."""
+    _, _, run = build_case(tag)
+    _, g64 = golden(tag)
+    o64 = run(torch.float64)
+    assert [o.shape for o in o64] == [g.shape for g in g64]
+    for k, (a, b) in enumerate(zip(o64, g64)):
+        assert np.abs(a - b).max() <= 1e-9 * max(1.0, np.abs(b).max()), (tag, k, np.abs(a - b).max())
 
 
 @pytest.mark.parametrize('tag', SMOOTH_CASES)

@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """Round profile on the GPU box, every workload of bench.py:
 
-    /usr/local/graft/bin/gpurun --timeout 1500 -- 'python tools/profile_round.py r04 [--workloads mpii,h36m,...] [--skip-pmc]'
+    /usr/local/graft/bin/gpurun --timeout 1500 -- 'python tools/profile_round.py r05 [--workloads mpii,h36m,...] [--skip-pmc]'
 
 Per workload W:
   1. `python bench.py --workload W` (tilings cached in gpurun_out/<tag>_tune_W.json)       -> <tag>_bench_line_W.json
@@ -119,6 +119,8 @@ def main():
     ap.add_argument('--skip-pmc', action='store_true')
     ap.add_argument('--skip-stats', action='store_true')
     ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--all-tilings', default='mpii',
+                    help='workloads whose dominant GEMM is PMC-profiled on all three <4,1,1,N> tilings (2 passes each)')
     args = ap.parse_args()
     os.makedirs(OUT, exist_ok=True)
     py, bench = sys.executable, os.path.join(ROOT, 'bench.py')
@@ -155,14 +157,15 @@ def main():
         # (3) PMC passes over the in-model launch of the main shape
         if args.skip_pmc:
             continue
-        # the autotuner alternates between near-equal tilings of the dominant pointwise GEMM from box to box: cover both
+        # the autotuner alternates between near-equal tilings of the dominant pointwise GEMM from box to box: cover ALL of
+        # them [r05: the driver's box picked <4,1,1,1>, which round 4 had not profiled -> `traffic: null`]
         variants = [(None, roof['kernel'])]
         head = 'gemm1x1_kernel<4, 1, 1, '
-        if roof['kernel'].startswith(head):
+        if roof['kernel'].startswith(head) and w in args.all_tilings.split(','):
             tn = roof['kernel'][len(head)]
-            other = {'3': (12, '2'), '2': (11, '3')}.get(tn)
-            if other:
-                variants.append((other[0], roof['kernel'].replace(head + tn, head + other[1], 1)))
+            for other, cfg in (('3', 11), ('2', 12), ('1', 13)):        # bench.TILES index + 9 (the LDS-DMA family)
+                if other != tn:
+                    variants.append((cfg, roof['kernel'].replace(head + tn, head + other, 1)))
         for cfg, kname in variants:
             e = pmc_entry(args, w, base, roof, cfg, kname)
             if e is not None:
