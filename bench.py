@@ -486,18 +486,41 @@ def timed(step, streams, steps, warmup, world, pairs=None):
         pairs.clear()
     if world > 1:
         dist.barrier()
+    host = 0.0
     t0 = time.perf_counter()
     for _ in range(steps):
+        h0 = time.perf_counter()
         step()
+        host += time.perf_counter() - h0
     drain()
+    t_local = time.perf_counter() - t0
     if world > 1:
         dist.barrier()
     dt = time.perf_counter() - t0
+    # this rank's own clock (before the closing barrier) and the host time it spent enqueueing: with the per-rank
+    # collective_us they decompose a multi-GPU step into compute, collective and launch cost
+    LAST_TIMED.update(rank_ms_per_step=1e3 * t_local / steps, host_enqueue_us_per_step=1e6 * host / steps)
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device='cuda')
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     return dt
+
+
+LAST_TIMED = {}
+
+
+def per_rank_table(world, collective_us):
+    """Every rank's {rank, ms_per_step (own clock), host_enqueue_us_per_step, collective_us} gathered to all ranks."""
+    import torch.distributed as dist
+    mine = dict(rank=int(os.environ.get('RANK', '0')), ms_per_step=round(LAST_TIMED.get('rank_ms_per_step', 0.0), 3),
+                host_enqueue_us_per_step=round(LAST_TIMED.get('host_enqueue_us_per_step', 0.0), 1),
+                collective_us=collective_us)
+    if world == 1:
+        return [mine]
+    table = [None] * world
+    dist.all_gather_object(table, mine)
+    return table
 
 
 def _free_port():
@@ -539,13 +562,16 @@ def dry_run(args, world, rank):
         us.append(1e6 * (time.perf_counter() - c0))
         frames = parallel.frames_view(buf).reshape(clips, T, J, C)
         assert all(bool((frames[:, r * tl:(r + 1) * tl] == r).all()) for r in range(world))
+    t_local = time.perf_counter() - t0
     if world > 1:
         dist.barrier()
     dt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
     if world > 1:
         dist.all_reduce(dt, op=dist.ReduceOp.MAX)
+    LAST_TIMED.update(rank_ms_per_step=1e3 * t_local / args.steps, host_enqueue_us_per_step=float(np.mean(us[args.warmup:])))
+    per_rank = per_rank_table(world, round(float(np.mean(us[args.warmup:])), 2))
     if rank == 0:
-        print(json.dumps({'metric': 'dry run of the multi-rank launcher (gloo, CPU): no product measurement',
+        print(json.dumps({'metric': 'dry run of the multi-rank launcher (gloo, CPU): no product measurement', 'per_rank': per_rank,
                           'dry_run': True, 'backend': 'gloo', 'value': round(clips * world * T * args.steps / float(dt), 1),
                           'unit': 'frames/s', 'n_gpus': world, 'rccl_ranks': world, 'steps': args.steps,
                           'warmup': args.warmup, 'ms_per_step': round(1e3 * float(dt) / args.steps, 3),
@@ -725,6 +751,7 @@ def main():
     dt = timed(step, streams, args.steps, args.warmup, world, pairs)
     if wl['clips']:
         collective_us = round(1e3 * float(np.mean([a.elapsed_time(b) for a, b in pairs])), 2)
+    per_rank = per_rank_table(world, collective_us)           # (a collective: every rank calls it)
 
     # sanity: outputs finite and in range
     pose = check()
@@ -816,6 +843,7 @@ def main():
             'roofline': roof,
         }
         out.update(extra)
+        out['per_rank'] = per_rank
         if collective_us is not None:
             out['collective_us'] = collective_us
             out['rccl_ranks'] = world

@@ -127,14 +127,16 @@ def split_frames(model, shards):
 # runtime
 # ---------------------------------------------------------------------------------------------------------
 
-def all_gather_rank_major(local, group=None, world=None, out=None):
+def all_gather_rank_major(local, group=None, world=None, out=None, always=False):
     """ONE collective: all-gather a [N, T_local, ...] tensor -> [G, N, T_local, ...] (rank-major, exactly what
     `all_gather_into_tensor` writes; no re-ordering pass).  Works on CUDA tensors (RCCL) and CPU tensors (gloo).
-    `out`: optional persistent destination of that shape.  With one rank the result is a view of `local`."""
+    `out`: optional persistent destination of that shape.  With one rank the result is a view of `local` -- unless
+    `always`: then the collective is issued even for a world of one (the RCCL call path, the persistent buffer and the
+    stream ordering around it are what a one-GPU test box can exercise of the multi-GPU leg)."""
     import torch
     import torch.distributed as dist
     world = dist.get_world_size(group) if world is None else world
-    if world == 1:
+    if world == 1 and not always:
         return local.unsqueeze(0)
     local = local.contiguous()
     shape = (world,) + tuple(local.shape)
@@ -179,7 +181,8 @@ class ShardedClipModel:
     may be injected: the CPU tests put oracle stand-ins there to exercise the collective and the bookkeeping with the
     gloo backend."""
 
-    def __init__(self, model, rank=None, world=None, group=None, frame_fn=None, head_fn=None):
+    def __init__(self, model, rank=None, world=None, group=None, frame_fn=None, head_fn=None, always_collective=False):
+        self.always_collective = bool(always_collective)     # issue the all-gather even for a world of one rank
         if rank is None or world is None:
             import torch.distributed as dist
             rank = dist.get_rank(group) if rank is None else rank
@@ -228,8 +231,9 @@ class ShardedClipModel:
         packed = self.frame_fn(x_local)
         if events is not None:
             events[0].record()
-        gathered = all_gather_rank_major(packed, self.group, self.world, out=self._gather_buf)   # [G, N, Tl, J, Cp]
-        if self.world > 1:
+        gathered = all_gather_rank_major(packed, self.group, self.world, out=self._gather_buf,
+                                         always=self.always_collective)                         # [G, N, Tl, J, Cp]
+        if self.world > 1 or self.always_collective:
             self._gather_buf = gathered
         if events is not None:
             events[1].record()

@@ -27,6 +27,10 @@ def test_bench_spawns_its_own_ranks():
     line = _one_json_line(r.stdout)
     assert line['n_gpus'] == 2 and line['rccl_ranks'] == 2 and line['steps'] == 3 and line['warmup'] == 1
     assert line['dry_run'] is True and line['value'] > 0 and line['collective_us'] > 0
+    # [r05] the per-rank decomposition a first multi-GPU run will be read by: every rank's own clock, host enqueue time
+    # and collective time
+    assert [r['rank'] for r in line['per_rank']] == [0, 1]
+    assert all(r['ms_per_step'] > 0 and r['collective_us'] > 0 and r['host_enqueue_us_per_step'] > 0 for r in line['per_rank'])
     for key in ('metric', 'unit', 'ms_per_step', 'higher_is_better', 'scaling', 'vs_baseline', 'dtype', 'data', 'config'):
         assert key in line
 
@@ -54,6 +58,16 @@ def test_rank_major_gather_view_orders_frames():
     assert g.shape == (1, 2, 3, 4, 5) and g.data_ptr() == x.data_ptr()
     assert torch.equal(parallel.frames_view(g).reshape(2, 3, 4, 5), x)
     assert torch.equal(parallel.all_gather_frames(x, world=1), x)
+    # `always`: the collective is really issued for a world of one (what tools/nccl_world1_check.py does under RCCL)
+    import torch.distributed as dist
+    from test_parallel_gloo import _free_port
+    dist.init_process_group('gloo', rank=0, world_size=1, init_method='tcp://127.0.0.1:%d' % _free_port())
+    try:
+        buf = torch.full((1, 2, 3, 4, 5), -1.0)
+        g2 = parallel.all_gather_rank_major(x, out=buf, always=True)
+        assert g2.data_ptr() == buf.data_ptr() and torch.equal(g2[0], x)
+    finally:
+        dist.destroy_process_group()
     # two "ranks" written rank-major by hand: rank r holds frames [r*Tl, (r+1)*Tl) of every clip
     full = torch.arange(2 * 6 * 4 * 5, dtype=torch.float32).reshape(2, 6, 4, 5)
     rank_major = torch.stack([full[:, 0:3], full[:, 3:6]])

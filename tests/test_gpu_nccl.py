@@ -23,3 +23,5 @@ def test_sharded_clip_model_over_rccl_world_of_one(hip_lib, cuda):
                          capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
     assert 'nccl world-1 OK: 11 outputs identical' in out.stdout
+    # [r05] SPNet-NTU at T = 32 through a real all_gather_into_tensor call (world of one, always_collective)
+    assert 'nccl world-1 SPNet-NTU T=32 OK: 12 outputs identical over 3 steps, packed channels 2634' in out.stdout, out.stdout[-1500:]

@@ -24,4 +24,28 @@ for a, b in zip(plain, sharded):
     assert np.array_equal(a, np.asarray(b)), float(np.abs(a - np.asarray(b)).max())
 t = torch.ones(4, device='cuda'); dist.all_reduce(t); dist.barrier()
 print('nccl world-1 OK: %d outputs identical, packed channels %d' % (len(plain), runner.info['packed_channels']))
+
+# [r05] SPNet-NTU at T = 32 (BASELINE configs[4]; consumers of the gathered tensors: spnet.py:219-235): the 2 634-channel
+# packed buffer goes through a REAL all_gather_into_tensor call (always_collective: a world of one would otherwise
+# short-cut to a view), the persistent gather buffer is re-used over three steps, and the head stage reads its strided
+# channel runs -- bit-identical to the plain model.
+if os.environ.get('DEEPHAR_NCCL_CHECK_SPNET', '1') != '0':
+    from deephar_amd import utils
+    from deephar_amd.config import ModelConfig
+    from deephar_amd.models import spnet
+    graph.reset_naming()
+    cfg = ModelConfig((32, 256, 256, 3), utils.pa17j3d, num_actions=[60], num_pyramids=2, action_pyramids=[1, 2],
+                      num_levels=4, pose_replica=False, num_pose_features=192, num_visual_features=192)
+    sp = spnet.build(cfg)
+    weights.init_synthetic(sp, seed=0)
+    xs = np.random.default_rng(5).uniform(-1, 1, (3, 1, 32, 256, 256, 3)).astype(np.float32)
+    runner = parallel.ShardedClipModel(sp, always_collective=True)
+    for step in range(3):
+        plain = sp.predict(xs[step], batch_size=1)
+        sharded = runner.predict(xs[step])
+        assert runner._gather_buf is not None and tuple(runner._gather_buf.shape[:3]) == (1, 1, 32)
+        for a, b in zip(plain, sharded):
+            assert np.array_equal(a, np.asarray(b)), (step, float(np.abs(a - np.asarray(b)).max()))
+    print('nccl world-1 SPNet-NTU T=32 OK: %d outputs identical over 3 steps, packed channels %d, gather buffer %s' % (
+        len(plain), runner.info['packed_channels'], tuple(runner._gather_buf.shape)))
 dist.destroy_process_group()
