@@ -6,12 +6,14 @@
 // at two 8-frame clips per call (exp/pennaction/eval_speed2d.py) 400 of the 621 launches of the last prediction
 // block's model are of this kind and ran 15-33 us each (profiles/r05_speed2d_first.json).
 //
-// Here a work-group of 4 / 8 / 16 waves owns the 32 x 32 tile and splits K into contiguous runs of k-group pairs
-// (8 k each: lanes lh = 0 / 1 take the k-groups 2 kp / 2 kp + 1).  Per chunk of eight pairs a lane issues ALL its
-// loads back to back -- A: the four consecutive channels of its pixel's tap (one 16-byte load; four dwords when
-// Cin % 4 != 0), B: the packed weights' 16-byte unit of its column -- and only then touches them: one memory round
-// trip per chunk, not one per pair [r05: round 2's kernel applied the BatchNormalization prologue inside the load
-// helper, i.e. waited for every pair before issuing the next -- 27 us for K = 1440].  The prologue's per-channel
+// Here a work-group of 4 / 8 / 16 waves owns a 16 x 16 output tile (v_mfma_f32_16x16x4_f32: the same MAC rate per SIMD as
+// the 32 x 32 form, four times as many work-groups -- a [2 clips x 8 x 8] x 160 map is 80 tiles on 80 CUs instead of 20 on
+// 20, and the A rows of a quad are 64 contiguous bytes) and splits K into contiguous runs of k-group quads (16 k each:
+// lane group lg = lane / 16 takes k-group 4 q + lg).  Per chunk of eight quads a lane issues ALL its loads back to back
+// -- A: the four consecutive channels of its pixel's tap (one 16-byte load; four dwords when Cin % 4 != 0), B: the
+// packed weights' 16-byte unit of its column -- and only then touches them: one memory round trip per chunk, not one per
+// group [r05: round 2's kernel applied the BatchNormalization prologue inside the load helper, i.e. waited for every
+// pair before issuing the next -- 27 us for K = 1440].  The prologue's per-channel
 // scale / shift sit in LDS (staged while the first chunk is in flight); (tap, channel) of a k-group comes from one
 // multiply-high, no integer divide.  The partial tiles are summed through LDS in wave order, then BN / residuals / ReLU.
 //
@@ -28,18 +30,18 @@ constexpr int SK_MAX_CIN = 4096; // prologue table in LDS: 2 x Cin floats
 template <int NWV, bool VEC>
 __global__ __launch_bounds__(NWV * 64) void conv_skinny_kernel(const ConvArgs p, const unsigned magic_cin, const unsigned magic_kw) {
   extern __shared__ __attribute__((aligned(16))) float sk_lds[];
-  float (*red)[16][64] = reinterpret_cast<float (*)[16][64]>(sk_lds);          // [NWV][16][64] partial tiles
-  float* pre_tab = sk_lds + NWV * 16 * 64;                                       // [2][Cin4]: scale, shift (BN prologue only)
+  float (*red)[4][64] = reinterpret_cast<float (*)[4][64]>(sk_lds);            // [NWV][4][64] partial tiles
+  float* pre_tab = sk_lds + NWV * 4 * 64;                                        // [2][Cin4]: scale, shift (BN prologue only)
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
-  const int li = lane & 31, lh = lane >> 5;
+  const int li = lane & 15, lg = lane >> 4;               // v_mfma_f32_16x16x4_f32: A[row li][k lg], B[k lg][col li]
   const int M = p.N * p.OH * p.OW;
-  const int tiles_n = (p.Cout + 31) / 32;
-  const int m0 = (blockIdx.x / tiles_n) * 32;
-  const int n0 = (blockIdx.x % tiles_n) * 32;
+  const int tiles_n = (p.Cout + 15) / 16;
+  const int m0 = (blockIdx.x / tiles_n) * 16;
+  const int n0 = (blockIdx.x % tiles_n) * 16;
   const bool aff = p.pre_scale != nullptr;
   const int cin4 = (p.Cin + 3) & ~3;
-  constexpr int SK_DEPTH = VEC ? 8 : 4;                   // k-group pairs in flight per wave (dword form: 4 loads per pair and half)
+  constexpr int SK_DEPTH = VEC ? 8 : 4;                   // k-group quads in flight per wave (dword form: 4 loads per quad and lane)
 
   // this lane's output pixel (A operand row) and its top-left input position
   int m = m0 + li;
@@ -49,15 +51,14 @@ __global__ __launch_bounds__(NWV * 64) void conv_skinny_kernel(const ConvArgs p,
   const int oh = rem / p.OW, ow = rem - oh * p.OW;
   const int ih0 = oh * p.SH - p.PT, iw0 = ow * p.SW - p.PL;
   const float* xf = p.x + (size_t)fr * p.H * p.W * p.ldx;
-  const float* wcol = p.w + (size_t)(n0 + li) * 4;        // packed [Kp / 4][Np][4]: unit (k-group, column)
-  const int pairs = p.Kp / 8;
-  const int per_wave = (pairs + NWV - 1) / NWV;
-  const int kp_begin = wave * per_wave;
-  const int kp_end = kp_begin + per_wave < pairs ? kp_begin + per_wave : pairs;
+  const int ncol = n0 + li < p.Np ? n0 + li : p.Np - 1;   // (Np is a multiple of 32: always in range; belt and braces)
+  const float* wcol = p.w + (size_t)ncol * 4;             // packed [Kp / 4][Np][4]: unit (k-group, column)
+  const int quads = p.Kp / 16;                            // 16 k each: lane group lg takes k-group 4 q + lg
+  const int per_wave = (quads + NWV - 1) / NWV;
+  const int q_begin = wave * per_wave;
+  const int q_end = q_begin + per_wave < quads ? q_begin + per_wave : quads;
 
-  f32x16 acc;
-#pragma unroll
-  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  f32x4v acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};     // two chains: a dependent 16x16x4 MFMA stalls 8 of 40 cycles
 
   // element k -> its address relative to xf, or -1 outside the image / past K (zero padding applies AFTER the prologue)
   auto locate = [&](int k, int& c) -> int {
@@ -71,15 +72,15 @@ __global__ __launch_bounds__(NWV * 64) void conv_skinny_kernel(const ConvArgs p,
   };
 
   bool tab_ready = !aff;
-  for (int kp0 = kp_begin; kp0 < kp_end || !tab_ready; kp0 += SK_DEPTH) {
+  for (int q0 = q_begin; q0 < q_end || !tab_ready; q0 += SK_DEPTH) {
     float4 fa[SK_DEPTH], fb[SK_DEPTH];
     int ch[SK_DEPTH];              // VEC: channel of the group's first element (table index); scalar: k of the first element
-    unsigned okm = 0;              // VEC: bit d = pair d inside the image; scalar: 4 bits per pair
+    unsigned okm = 0;              // VEC: bit d = group d inside the image; scalar: 4 bits per group
 #pragma unroll
     for (int d = 0; d < SK_DEPTH; ++d) {
-      const int kp = kp0 + d;
-      const bool live = kp < kp_end;
-      const int kg = 2 * (live ? kp : 0) + lh;
+      const int q = q0 + d;
+      const bool live = q < q_end;
+      const int kg = 4 * (live ? q : 0) + lg;
       fb[d] = *reinterpret_cast<const float4*>(wcol + (size_t)kg * p.Np * 4);
       const int k0 = 4 * kg;
       if constexpr (VEC) {
@@ -138,47 +139,36 @@ __global__ __launch_bounds__(NWV * 64) void conv_skinny_kernel(const ConvArgs p,
           a[j] = ((okm >> (4 * d + j)) & 1u) ? a[j] : 0.f;
         }
       }
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[0], fb[d].x, acc, 0, 0, 0);     // a dead pair is zeros on the A side
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[1], fb[d].y, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[2], fb[d].z, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[3], fb[d].w, acc, 0, 0, 0);
+      // MFMA j multiplies element j of every lane group's k-group: k = 4 (4 q + lg) + j (a dead group is zeros on the A side)
+      acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[0], fb[d].x, acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[1], fb[d].y, acc1, 0, 0, 0);
+      acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[2], fb[d].z, acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[3], fb[d].w, acc1, 0, 0, 0);
     }
   }
 
-  // C layout of the 32x32 tile: register r of lane (li, lh) = row (r & 3) + 8 (r >> 2) + 4 lh, column li.  Thread t sums and
-  // writes the outputs t, t + NWV * 64, ...; their BN / residual values are fetched BEFORE the partial tiles go through
-  // LDS, so the epilogue's global round trip runs under the reduction instead of behind it.
-  constexpr int NOUT = (16 * 64) / (NWV * 64);
+  // C layout of the 16x16 tile: register r of lane (li, lg) = row 4 lg + r, column li.  Thread t < 256 sums and writes
+  // output t; its BN / residual values are fetched BEFORE the partial tiles go through LDS, so the epilogue's global round
+  // trip runs under the reduction instead of behind it.
   const int ohw = p.OH * p.OW;
-  float psc[NOUT], psh[NOUT], r1v[NOUT], r2v[NOUT];
-#pragma unroll
-  for (int i = 0; i < NOUT; ++i) {
-    const int idx = tid + i * NWV * 64;
-    const int r = idx >> 6, l = idx & 63;
-    const int row = (r & 3) + 8 * (r >> 2) + 4 * (l >> 5), col = l & 31;
-    const int mm = m0 + row, n = n0 + col;
-    const bool ok = mm < M && n < p.Cout;
-    const int mc = ok ? mm : 0, nc = ok ? n : 0;
-    psc[i] = p.post_scale != nullptr ? p.post_scale[nc] : 1.f;
-    psh[i] = p.post_scale != nullptr ? p.post_shift[nc] : 0.f;
-    r1v[i] = p.res1 != nullptr ? p.res1[(size_t)mc * p.ldr1 + nc] : 0.f;
-    r2v[i] = (p.res2 != nullptr && !p.up2) ? p.res2[(size_t)mc * p.ldr2 + nc] : 0.f;
+  const int er = tid >> 6, el = tid & 63;                                  // (tid < 256: waves 0 .. 3)
+  const int mm = m0 + 4 * (el >> 4) + er, n = n0 + (el & 15);
+  const bool mine = tid < 256 && mm < M && n < p.Cout;
+  float psc = 1.f, psh = 0.f, r1v = 0.f, r2v = 0.f;
+  if (mine) {
+    if (p.post_scale != nullptr) { psc = p.post_scale[n]; psh = p.post_shift[n]; }
+    if (p.res1 != nullptr) r1v = p.res1[(size_t)mm * p.ldr1 + n];
+    if (p.res2 != nullptr && !p.up2) r2v = p.res2[(size_t)mm * p.ldr2 + n];
   }
 #pragma unroll
-  for (int r = 0; r < 16; ++r) red[wave][r][lane] = acc[r];
+  for (int r = 0; r < 4; ++r) red[wave][r][lane] = acc0[r] + acc1[r];
   __syncthreads();
+  if (mine) {
+    float t = red[0][er][el];
 #pragma unroll
-  for (int i = 0; i < NOUT; ++i) {
-    const int idx = tid + i * NWV * 64;
-    const int r = idx >> 6, l = idx & 63;
-    const int row = (r & 3) + 8 * (r >> 2) + 4 * (l >> 5), col = l & 31;
-    const int mm = m0 + row, n = n0 + col;
-    if (mm >= M || n >= p.Cout) continue;
-    float t = red[0][r][l];
-#pragma unroll
-    for (int w = 1; w < NWV; ++w) t += red[w][r][l];
-    if (p.post_scale != nullptr) t = t * psc[i] + psh[i];
-    if (p.res1 != nullptr) t += r1v[i];
+    for (int w = 1; w < NWV; ++w) t += red[w][er][el];
+    if (p.post_scale != nullptr) t = t * psc + psh;
+    if (p.res1 != nullptr) t += r1v;
     if (p.up2) {
       const int f2 = mm / ohw;
       const int rm = mm - f2 * ohw;
@@ -192,7 +182,7 @@ __global__ __launch_bounds__(NWV * 64) void conv_skinny_kernel(const ConvArgs p,
         p.y[mo * p.ldy + n] = o;
       }
     } else {
-      if (p.res2 != nullptr) t += r2v[i];
+      if (p.res2 != nullptr) t += r2v;
       if (p.post_relu) t = fmaxf(t, 0.f);
       p.y[(size_t)mm * p.ldy + n] = t;
     }
@@ -203,8 +193,8 @@ template <int NWV>
 int launch_skinny(const ConvArgs& a, unsigned tiles, bool vec, hipStream_t s) {
   const unsigned magic_cin = (unsigned)((1ull << 32) / (unsigned)a.Cin + 1ull);       // k / Cin = umulhi(k, magic), k * Cin < 2^32
   const unsigned magic_kw = (1u << 16) / (unsigned)a.KW + 1u;                          // tap / KW for tap < 2^8
-  const size_t lds = ((size_t)NWV * 16 * 64 + (a.pre_scale != nullptr ? (size_t)2 * ((a.Cin + 3) & ~3) : 0)) * sizeof(float);
-  constexpr int lds_max = (NWV * 16 * 64 + 2 * SK_MAX_CIN) * (int)sizeof(float);     // <= 96 KB of the CU's 160
+  const size_t lds = ((size_t)NWV * 4 * 64 + (a.pre_scale != nullptr ? (size_t)2 * ((a.Cin + 3) & ~3) : 0)) * sizeof(float);
+  constexpr int lds_max = (NWV * 4 * 64 + 2 * SK_MAX_CIN) * (int)sizeof(float);      // <= 48 KB
   if (vec) {
     static LdsLimit lim;
     if (lds_max > 64 * 1024) lim.raise((const void*)conv_skinny_kernel<NWV, true>, lds_max);
@@ -229,16 +219,16 @@ bool conv_is_skinny(const ConvArgs& a) {
          (long long)a.K * a.Cin < (1ll << 31);
 }
 
-// waves per tile: from K alone (8 k per pair, eight pairs per wave and chunk)
+// waves per tile: from K alone (16 k per quad, eight quads per wave and chunk)
 int conv_skinny_waves(int Kp) {
-  const int pairs = Kp / 8;
-  return pairs > 64 ? 16 : (pairs > 16 ? 8 : 4);
+  const int quads = Kp / 16;
+  return quads > 32 ? 16 : (quads > 8 ? 8 : 4);
 }
 
 int launch_conv_splitk(const ConvArgs& a, hipStream_t s) {
   const long long M = (long long)a.N * a.OH * a.OW;
-  const long long tiles = ((M + 31) / 32) * ((a.Cout + 31) / 32);
-  if (tiles <= 0 || tiles > 0x7fffffffLL || (long long)a.H * a.W * a.ldx > 0x7fffffffLL) return DH_EINVAL;
+  const long long tiles = ((M + 15) / 16) * ((a.Cout + 15) / 16);
+  if (tiles <= 0 || tiles > 0x7fffffffLL || (long long)a.H * a.W * a.ldx > 0x7fffffffLL || a.Kp % 16 != 0) return DH_EINVAL;
   auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
   // (the vector form is a property of the layer wherever the engine lays tensors out 16-byte aligned; both forms load
   //  the same values and run the same arithmetic: same bits)
