@@ -410,6 +410,8 @@ def speed2d_protocol(full_model, args, tune_table):
         m = Model(full_model.input, full_model.outputs[2 * b:2 * b + 2])
         if args.streams is not None:
             m.num_streams = args.streams
+        if args.stream_policy is not None:
+            m.stream_policy = args.stream_policy
         m.executor.tune_table = tune_table
         m.executor.use_graph = not args.no_graph
         m.predict(x[0:1])                                           # "Warming up the new model."
@@ -601,6 +603,9 @@ def main():
     ap.add_argument('--dump-steps', default=None, help='write the per-kernel profile (JSON) to this path')
     ap.add_argument('--streams', type=int, default=None,
                     help='HIP streams for independent model branches (default: the engine default)')
+    ap.add_argument('--stream-policy', choices=('list', 'tail'), default=None,
+                    help="with --streams 2: 'tail' = the second stream runs a suffix of the step list (SPNet's action stream "
+                         "beside its pose stream; engine/schedule.py)")
     ap.add_argument('--input', choices=('f32', 'u8'), default='f32',
                     help="mpii: f32 = normalised float frames resident in HBM (what the reference's predict() is "
                          "handed); u8 = raw uint8 frames resident in HBM, normalised inside the first convolution")
@@ -656,6 +661,8 @@ def main():
         args.no_bf16x3 = args.no_clip_leg = True
     if args.streams is not None:
         model.num_streams = args.streams
+    if args.stream_policy is not None:
+        model.stream_policy = args.stream_policy
     if args.gemm is not None:
         model.gemm_precision = args.gemm
 
@@ -720,6 +727,8 @@ def main():
         model = Model(full_model.input, full_model.outputs[2 * (nb - 1):2 * nb])
         if args.streams is not None:
             model.num_streams = args.streams
+        if args.stream_policy is not None:
+            model.stream_policy = args.stream_policy
         args.no_bf16x3 = args.no_clip_leg = True
 
     if not wl['clips']:

@@ -136,8 +136,9 @@ class _Lazy:
 
 
 class Planner:
-    def __init__(self, inputs, outputs, nstreams=1):
+    def __init__(self, inputs, outputs, nstreams=1, stream_policy='list'):
         self.nstreams = nstreams
+        self.stream_policy = stream_policy
         self.producer = {}            # id(Value) -> the Step that writes it
         self.g_inputs = inputs
         self.g_outputs = outputs
@@ -310,7 +311,7 @@ class Planner:
             self.plan.outputs.append(v)
         self._collect_params()
         from . import schedule
-        schedule.finalize(self.plan, self.nstreams)
+        schedule.finalize(self.plan, self.nstreams, self.stream_policy)
         return self.plan
 
     # ---- R3: add([a, UpSampling2D(b)]) as the second residual of the convolution that produces a --------------
@@ -855,9 +856,11 @@ class Planner:
         self.plan.params = out
 
 
-def build_plan(inputs, outputs, nstreams=1, gemm_precision='f32'):
+def build_plan(inputs, outputs, nstreams=1, gemm_precision='f32', stream_policy='list'):
     if gemm_precision not in ('f32', 'bf16x3'):
         raise ValueError("gemm_precision must be 'f32' or 'bf16x3', got %r" % (gemm_precision,))
-    plan = Planner(inputs, outputs, nstreams).run()
+    if stream_policy not in ('list', 'tail'):
+        raise ValueError("stream_policy must be 'list' or 'tail', got %r" % (stream_policy,))
+    plan = Planner(inputs, outputs, nstreams, stream_policy).run()
     plan.gemm_precision = gemm_precision
     return plan

@@ -104,6 +104,77 @@ def stream_unassigned(k, j):
     return k > j
 
 
+def assign_streams_tail(plan, deps, items=2):
+    """Two streams for the LATENCY regime (a couple of clips per call: exp/pennaction/eval_speed2d.py).  Stream 1 takes a
+    SUFFIX A = steps [s, n) of the planner's order: a suffix of a topological order is closed under "is read by", so every
+    cross-stream dependency points from stream 0 to stream 1 -- one direction, no ping-pong (the list scheduler above
+    produced 367 cross-stream waits on the last block's model of that protocol and ran slower than one stream).  In SPNet
+    the suffix is the action stream: nothing in the pose stream reads it (spnet.py:219-248) and the planner emits it behind
+    the pose blocks.  Inside A the steps are RE-ORDERED by a list scheduler (earliest ready first): the planner walks the
+    action heads from the last prediction block back to the first, but the front end of head k (pose / visual feature
+    convolutions, kronecker pooling) only needs pose block k.  s minimises the simulated makespan under a per-step cost
+    of a launch floor plus the step's arithmetic / bytes for `items` batch items; no split is made when it would not save
+    5 % of the serial time.  -> (stream per step, new order of the steps) -- the order stays topological."""
+    import heapq
+    n = len(plan.steps)
+    stream, order = [0] * n, list(range(n))
+    if n < 8:
+        return stream, order
+    cost = [5.0 + (st.flops(items) / 60e12 + st.bytes(items) / 2e12) * 1e6 for st in plan.steps]
+    consumers = [[] for _ in range(n)]
+    for j, d in enumerate(deps):
+        for i in d:
+            consumers[i].append(j)
+    fin0 = [0.0] * n                      # finish time of step i if steps [0, i] run back to back on stream 0
+    t = 0.0
+    for i in range(n):
+        t += cost[i]
+        fin0[i] = t
+    serial = t
+
+    def simulate(s):
+        """stream 1 = list schedule of [s, n): -> (makespan, [(start, step)])"""
+        indeg = [0] * n
+        ready_at = [0.0] * n
+        heap = []
+        for j in range(s, n):
+            for i in deps[j]:
+                if i >= s:
+                    indeg[j] += 1
+                else:
+                    ready_at[j] = max(ready_at[j], fin0[i])
+            if indeg[j] == 0:
+                heapq.heappush(heap, (ready_at[j], j))
+        t1, starts = 0.0, []
+        while heap:
+            r, j = heapq.heappop(heap)
+            start = max(t1, r)
+            t1 = start + cost[j]
+            starts.append((start, j))
+            for k in consumers[j]:
+                ready_at[k] = max(ready_at[k], t1)
+                indeg[k] -= 1
+                if indeg[k] == 0:
+                    heapq.heappush(heap, (ready_at[k], k))
+        return max(fin0[s - 1], t1), starts
+
+    best_s, best, best_starts = 0, serial, None
+    for s in range(1, n):
+        span, starts = simulate(s)
+        if span < best:
+            best_s, best, best_starts = s, span, starts
+    if best_s == 0 or best > 0.95 * serial:
+        return stream, order
+    start = [fin0[i] - cost[i] for i in range(n)]
+    for st_, j in best_starts:
+        start[j] = st_
+        stream[j] = 1
+    # merged launch order: by simulated start time (a step starts after everything it reads has finished, costs are
+    # positive: the order is topological); stream-0 steps keep their relative order
+    order = sorted(range(n), key=lambda j: (start[j], j))
+    return [stream[j] for j in order], order
+
+
 def happens_before(n, deps, stream):
     """reach[i] = bitmask of steps that are ordered after step i (descendants in deps + same-stream order)."""
     succ = [[] for _ in range(n)]
@@ -185,16 +256,36 @@ def allocate(plan, reach):
     plan.arena_items = max((b.offset + b.items for b in plan.bufs), default=0)
 
 
-def finalize(plan, nstreams=1):
-    """Fill step.stream / step.wait (cross-stream dependencies) and place every buffer in the arena."""
+def finalize(plan, nstreams=1, policy='list'):
+    """Fill step.stream / step.wait (cross-stream dependencies) and place every buffer in the arena.
+    policy: 'list' = the list scheduler (throughput regime: branches of an hourglass), 'tail' = assign_streams_tail (two
+    streams, latency regime)."""
     deps = compute_deps(plan)
-    stream = assign_streams(plan, deps, nstreams)
+    if policy == 'tail' and nstreams >= 2:
+        stream, order = assign_streams_tail(plan, deps)
+        if order != list(range(len(order))):
+            plan.steps[:] = [plan.steps[j] for j in order]
+            deps = compute_deps(plan)
+    else:
+        stream = assign_streams(plan, deps, nstreams)
     n = len(plan.steps)
     reach = happens_before(n, deps, stream)
+    # streams are in-order queues: waiting for step i of another stream covers every earlier step of that stream, and a
+    # wait made by an earlier step of the SAME stream still holds -- only the newest dependency per source stream is an
+    # event wait, and only if nothing on this stream waited that far already
+    waited = {}
     for j, s in enumerate(plan.steps):
         s.stream = stream[j]
         s.deps = deps[j]
-        s.wait = [i for i in deps[j] if stream[i] != stream[j]]
+        newest = {}
+        for i in deps[j]:
+            if stream[i] != stream[j]:
+                newest[stream[i]] = max(newest.get(stream[i], -1), i)
+        s.wait = []
+        for src, i in sorted(newest.items()):
+            if waited.get((stream[j], src), -1) < i:
+                s.wait.append(i)
+                waited[(stream[j], src)] = i
     # steps whose completion somebody on another stream waits for need an event
     needs_event = set(i for s in plan.steps for i in s.wait)
     for j, s in enumerate(plan.steps):

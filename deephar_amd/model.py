@@ -41,6 +41,10 @@ class Model:
         # convolutions (planner R3) one stream is 2 % faster than two on the MPII model, 12 % on the PennAction merge
         # model and 7 % on SPNet-NTU (frame-sharded stages)
         self.num_streams = max(1, int(__import__('os').environ.get('DEEPHAR_STREAMS', '1')))
+        # how steps are spread when num_streams > 1: 'list' = the list scheduler (branches of an hourglass; throughput
+        # regime), 'tail' = two streams, the second runs a suffix of the step list -- SPNet's action stream beside its pose
+        # stream -- for the latency regime of a couple of clips per call (engine/schedule.py: assign_streams_tail)
+        self.stream_policy = __import__('os').environ.get('DEEPHAR_STREAM_POLICY', 'list')
         # uint8 inputs are raw frames: predict() normalises them on the GPU exactly like the reference's loaders do
         # on the host (utils/transform.normalize_channels(frame, channel_power), transform.py:212-231)
         self.channel_power = 1
@@ -71,6 +75,7 @@ class Model:
 
     gemm_precision = _engine_option('gemm_precision')
     num_streams = _engine_option('num_streams')
+    stream_policy = _engine_option('stream_policy')
     del _engine_option
 
     # ---- Keras-like attributes -----------------------------------------------------------------------
@@ -202,7 +207,7 @@ class Model:
         if self._plan is None:
             from .engine.planner import build_plan
             self._plan = build_plan(self.inputs, self.outputs, nstreams=self.num_streams,
-                                    gemm_precision=self.gemm_precision)
+                                    gemm_precision=self.gemm_precision, stream_policy=self.stream_policy)
         return self._plan
 
     @property

@@ -152,6 +152,12 @@ def test_multi_stream_plans_are_bit_identical(hip_lib, cuda):
     sp.num_streams = 2
     for a, b in zip(one, sp.predict(clips, batch_size=1)):
         assert np.array_equal(a, b)
+    # [r05] the 'tail' policy of the latency regime: the action stream on a second stream, re-ordered by readiness
+    sp.stream_policy = 'tail'
+    assert sp.plan.nstreams == 2 and all(len(s.wait) <= 1 for s in sp.plan.steps)
+    for rep in range(2):                                            # capture, then replay
+        for a, b in zip(one, sp.predict(clips, batch_size=1)):
+            assert np.array_equal(a, b)
 
 
 def test_predict_accepts_float64_and_partial_batches(hip_lib, cuda):

@@ -221,6 +221,57 @@ def test_planner_r3_spares_split_k_producers():
     assert not any(s.attrs.get('res2_down') for s in plan.steps if s.kind == 'conv')
 
 
+def test_tail_stream_policy_is_one_directional_and_sound():
+    """Model.stream_policy = 'tail' (engine/schedule.py: assign_streams_tail; the latency regime of
+    exp/pennaction/eval_speed2d.py): stream 1 runs SPNet's action stream, re-ordered by readiness -- the step order stays
+    topological, every cross-stream dependency points from stream 0 to stream 1 and is waited for at most once per step,
+    nothing on stream 0 reads stream 1, and no two buffers that may be live together share arena space."""
+    from deephar_amd import graph, utils
+    from deephar_amd.config import ModelConfig
+    from deephar_amd.engine import schedule
+    from deephar_amd.models import spnet
+
+    def build(policy):
+        graph.reset_naming()
+        cfg = ModelConfig((8, 128, 128, 3), utils.pa16j2d, num_actions=[15], num_pyramids=2, action_pyramids=[1, 2],
+                          num_levels=4, pose_replica=True, num_pose_features=160, num_visual_features=160)
+        m = spnet.build(cfg)
+        m.num_streams, m.stream_policy = 2, policy
+        return m.plan
+    one = build('list')
+    plan = build('tail')
+    assert plan.nstreams == 2 and sorted(s.name or s.kind for s in plan.steps) == sorted(s.name or s.kind for s in one.steps)
+    deps = schedule.compute_deps(plan)
+    stream = [s.stream for s in plan.steps]
+    assert all(i < j for j, d in enumerate(deps) for i in d)                       # still a topological order
+    assert all(not (stream[j] == 0 and stream[i] == 1) for j, d in enumerate(deps) for i in d)
+    waits = [(j, w) for j, s in enumerate(plan.steps) for w in s.wait]
+    assert waits and all(stream[j] == 1 and stream[w] == 0 and plan.steps[w].record for j, w in waits)
+    assert len(waits) < sum(len(s.wait) for s in one.steps) / 4                    # (the list scheduler ping-pongs)
+    # every cross-stream dependency is covered by a wait of this step or of an earlier step on the same stream
+    covered = -1
+    for j, d in enumerate(deps):
+        if stream[j] == 1:
+            covered = max([covered] + list(plan.steps[j].wait))
+            assert all(i <= covered for i in d if stream[i] == 0), j
+    # memory plan: buffers overlapping in space are ordered by happens-before
+    reach = schedule.happens_before(len(plan.steps), deps, stream)
+    acc = {}
+    for j, s in enumerate(plan.steps):
+        for v in list(s.ins.values()) + list(s.outs.values()):
+            if v is not None:
+                acc.setdefault(id(v.buf), (v.buf, set()))[1].add(j)
+    bufs = list(acc.values())
+    for x, (a, sa) in enumerate(bufs):
+        for b, sb in bufs[x + 1:]:
+            if a.pinned or b.pinned or a.kind == 'input' or b.kind == 'input':
+                continue
+            if not (a.offset + a.items <= b.offset or b.offset + b.items <= a.offset):
+                ab = all(reach[i] >> j & 1 for i in sa for j in sb)
+                ba = all(reach[j] >> i & 1 for i in sa for j in sb)
+                assert ab or ba, (a.offset, b.offset)
+
+
 def test_planner_pooled_output_rule(monkeypatch):
     """R7: the 32-column MaxPooling2D becomes a second output of the convolution that feeds it; same algorithmic FLOPs,
     one launch and one full-resolution read less per block, and the memory plan stays sound (DEEPHAR_FUSE_POOL=0: off)."""
