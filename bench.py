@@ -18,6 +18,8 @@ Workloads (BASELINE.json `configs`):
               Model(full.input, full.outputs[2b:2b+2]), one warm-up predict, then 250 clips through
               predict(x, batch_size=2) on HOST arrays, wall clock -> `speed2d.fps_per_block` (18 entries).  A step of the
               contract line (`value`) is one device-resident forward of the LAST block's model on 2 clips = 16 frames.
+              Runs with the engine's latency-regime setting (Model.num_streams = 2, stream_policy = 'tail') unless
+              --streams / --stream-policy say otherwise.
               Clip workloads are FRAME-SHARDED: every rank runs T/N frames of all N x clips_per_gpu clips through the
               frame stage (conv stack + decoder + kronecker pooling), ONE RCCL all-gather of the packed
               [clips, T/N, J, C] tensor, then the (tiny) action head replicated on every rank -- all device resident
@@ -659,6 +661,11 @@ def main():
     model = wl['build'](args.blocks) if args.workload == 'mpii' else wl['build']()
     if args.workload in ('h36m', 'speed2d'):
         args.no_bf16x3 = args.no_clip_leg = True
+    if args.workload == 'speed2d' and args.streams is None and args.stream_policy is None:
+        # the latency regime's engine setting (what INTEGRATION.md recommends for a couple of clips per call): SPNet's action
+        # stream on a second stream, one-directional dependencies (engine/schedule.py: assign_streams_tail); measured
+        # 6.24 -> 5.01 ms per call, bit-identical.  `--streams 1` gives the one-stream number.
+        args.streams, args.stream_policy = 2, 'tail'
     if args.streams is not None:
         model.num_streams = args.streams
     if args.stream_policy is not None:

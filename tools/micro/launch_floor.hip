@@ -63,7 +63,16 @@ static int time_graph(hipStream_t s, hipEvent_t e0, hipEvent_t e1, int N, int RE
   CK(hipEventRecord(e1, s));
   CK(hipEventSynchronize(e1));
   float ms; CK(hipEventElapsedTime(&ms, e0, e1));
-  printf("%-72s graph %6.2f us/node\n", what, ms * 1e3 / (REP * N));
+  // host cost of hipGraphLaunch itself: the GPU idle before the call, wall clock around the call alone
+  double host = 0;
+  for (int r = 0; r < 5; ++r) {
+    CK(hipStreamSynchronize(s));
+    auto t0 = std::chrono::steady_clock::now();
+    CK(hipGraphLaunch(ge, s));
+    host += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
+  }
+  CK(hipStreamSynchronize(s));
+  printf("%-72s graph %6.2f us/node   host: hipGraphLaunch %6.2f us/node\n", what, ms * 1e3 / (REP * N), host / (5 * N));
   (void)hipGraphExecDestroy(ge); (void)hipGraphDestroy(g);
   return 0;
 }
@@ -170,6 +179,21 @@ int main() {
       hipLaunchKernelGGL(bump5, dim3(20), dim3(256), 0, s, x, at(37), at(91), at(153), at(211), n20);
     });
     (void)hipFree(huge);
+  }
+  // two chains in ONE graph (fork / join through events, as a multi-stream plan is captured): per node of BOTH chains
+  {
+    hipStream_t s2;
+    CK(hipStreamCreateWithFlags(&s2, hipStreamNonBlocking));
+    hipEvent_t fork, join;
+    CK(hipEventCreateWithFlags(&fork, hipEventDisableTiming)); CK(hipEventCreateWithFlags(&join, hipEventDisableTiming));
+    float* x2 = x + (1 << 20);
+    bool first = true;
+    time_graph(s, e0, e1, N, REP, "two independent chains of N/2 nodes on two captured streams, 20 x 256", [&](int i) {
+      if (first) { (void)hipEventRecord(fork, s); (void)hipStreamWaitEvent(s2, fork, 0); first = false; }
+      if (i & 1) hipLaunchKernelGGL(bump, dim3(20), dim3(256), 0, s2, x2, n20);
+      else hipLaunchKernelGGL(bump, dim3(20), dim3(256), 0, s, x, n20);
+      if (i == N - 1) { (void)hipEventRecord(join, s2); (void)hipStreamWaitEvent(s, join, 0); first = true; }
+    });
   }
   // a tiny kernel that READS 256 KB the previous (tiny) node did not write: cold after the boundary's invalidate?
   time_graph(s, e0, e1, N, REP, "tiny kernel reading 1 MB written long ago (sweep grid 512 x 256, read-modify-write)", [&](int) {
