@@ -115,7 +115,7 @@ def pmc_entry(args, w, base, roof, cfg, kname):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('tag')
-    ap.add_argument('--workloads', default='mpii,h36m,penn_merge,ntu_spnet')
+    ap.add_argument('--workloads', default='mpii,h36m,penn_merge,ntu_spnet,speed2d')
     ap.add_argument('--skip-pmc', action='store_true')
     ap.add_argument('--skip-stats', action='store_true')
     ap.add_argument('--steps', type=int, default=20)
