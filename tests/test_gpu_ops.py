@@ -526,6 +526,8 @@ def test_conv2d_second_residual_at_half_resolution(case, hip_lib, cuda):
     up = np.repeat(np.repeat(r2, 2, axis=1), 2, axis=2)
     d = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(cuda)
     kw = dict(pre_relu=relu, post_scale=d(sc), post_shift=d(sh), res1=d(r1))
+    from deephar_amd.engine.planner import split_k_rule
+    skinny = split_k_rule(h * w, cin, cout, cin)      # fp32 layers on the skinny-conv kernel have no half-resolution residual
     for split in (False, True):
         if split and cout % 4:
             continue
@@ -540,12 +542,15 @@ def test_conv2d_second_residual_at_half_resolution(case, hip_lib, cuda):
                 continue
             assert torch.equal(got, want), (split, cfg)
             done += 1
-        assert done >= 4
+        # (the planner never asks a skinny layer for it: test_planner_r3_spares_split_k_producers; the library says
+        #  DH_EUNSUPPORTED on every tiling)
+        assert done == 0 if (skinny and not split) else done >= 4
     xin = torch.from_numpy(x).double()
     ref = O.conv2d(O.relu(xin) if relu else xin, torch.from_numpy(k).double(), (1, 1), 'same')
     ref = ref * torch.from_numpy(sc).double() + torch.from_numpy(sh).double() + torch.from_numpy(r1).double() + \
         torch.from_numpy(up).double()
-    _close(F.conv2d(d(x), k, res2=d(r2), res2_down=True, **kw), ref, atol=5e-5, what='res2_down')
+    if not skinny:
+        _close(F.conv2d(d(x), k, res2=d(r2), res2_down=True, **kw), ref, atol=5e-5, what='res2_down')
     with pytest.raises(Exception):
         F.conv2d(d(x), k, res2=d(r2), res2_down=True, up2=True, **kw)
 
