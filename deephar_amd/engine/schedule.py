@@ -104,23 +104,30 @@ def stream_unassigned(k, j):
     return k > j
 
 
-def assign_streams_tail(plan, deps, items=2):
-    """Two streams for the LATENCY regime (a couple of clips per call: exp/pennaction/eval_speed2d.py).  Stream 1 takes a
+def assign_streams_tail(plan, deps, items=2, nstreams=2):
+    """Streams for the LATENCY regime (a couple of clips per call: exp/pennaction/eval_speed2d.py).  Stream 1 takes a
     SUFFIX A = steps [s, n) of the planner's order: a suffix of a topological order is closed under "is read by", so every
     cross-stream dependency points from stream 0 to stream 1 -- one direction, no ping-pong (the list scheduler above
     produced 367 cross-stream waits on the last block's model of that protocol and ran slower than one stream).  In SPNet
     the suffix is the action stream: nothing in the pose stream reads it (spnet.py:219-248) and the planner emits it behind
     the pose blocks.  Inside A the steps are RE-ORDERED by a list scheduler (earliest ready first): the planner walks the
     action heads from the last prediction block back to the first, but the front end of head k (pose / visual feature
-    convolutions, kronecker pooling) only needs pose block k.  s minimises the simulated makespan under a per-step cost
-    of a launch floor plus the step's arithmetic / bytes for `items` batch items; no split is made when it would not save
-    5 % of the serial time.  -> (stream per step, new order of the steps) -- the order stays topological."""
+    convolutions, kronecker pooling) only needs pose block k.
+    With nstreams >= 3, A is split once more: C = some step x of A and everything in A that (transitively) reads it goes
+    to stream 2, the rest F = A - C stays on stream 1 -- again one direction (C reads F and stream 0; F reads stream 0
+    only).  For SPNet, C is the chain that carries the action features from head to head (spnet.py:117-131) and F the
+    heads' front ends, which then run ahead of the chain.
+    s and x minimise the simulated makespan under a per-step cost of a launch floor plus the step's arithmetic / bytes
+    for `items` batch items; no split is made when it would not save 5 % of the serial time.
+    -> (stream per step, new order of the steps) -- the order stays topological."""
     import heapq
     n = len(plan.steps)
     stream, order = [0] * n, list(range(n))
     if n < 8:
         return stream, order
-    cost = [5.0 + (st.flops(items) / 60e12 + st.bytes(items) / 2e12) * 1e6 for st in plan.steps]
+    # (calibrated on the speed2d forward, profiles/r05_steps_speed2d.json: ~7.5 us per small launch in a graph, the entry
+    #  flow's big convolutions at ~90 TFLOP/s)
+    cost = [7.5 + max(st.flops(items) / 90e12, st.bytes(items) / 3e12) * 1e6 for st in plan.steps]
     consumers = [[] for _ in range(n)]
     for j, d in enumerate(deps):
         for i in d:
@@ -132,11 +139,13 @@ def assign_streams_tail(plan, deps, items=2):
         fin0[i] = t
     serial = t
 
-    def simulate(s):
-        """stream 1 = list schedule of [s, n): -> (makespan, [(start, step)])"""
+    def simulate(s, chain=None, bound=float('inf')):
+        """steps [s, n) list-scheduled (earliest ready first) on stream 1 -- and, for the steps in `chain`, on stream 2:
+        -> (makespan, {step: (start, stream)})"""
         indeg = [0] * n
         ready_at = [0.0] * n
-        heap = []
+        heaps = ([], [])
+        which = (lambda j: 1 if chain is not None and j in chain else 0)
         for j in range(s, n):
             for i in deps[j]:
                 if i >= s:
@@ -144,31 +153,50 @@ def assign_streams_tail(plan, deps, items=2):
                 else:
                     ready_at[j] = max(ready_at[j], fin0[i])
             if indeg[j] == 0:
-                heapq.heappush(heap, (ready_at[j], j))
-        t1, starts = 0.0, []
-        while heap:
-            r, j = heapq.heappop(heap)
-            start = max(t1, r)
-            t1 = start + cost[j]
-            starts.append((start, j))
+                heapq.heappush(heaps[which(j)], (ready_at[j], j))
+        clock, placed = [0.0, 0.0], {}
+        while heaps[0] or heaps[1]:
+            # the queue whose head can start first
+            cand = [(max(clock[q], heaps[q][0][0]), q) for q in (0, 1) if heaps[q]]
+            _, q = min(cand)
+            r, j = heapq.heappop(heaps[q])
+            start = max(clock[q], r)
+            clock[q] = start + cost[j]
+            if clock[q] >= bound:
+                return bound, None
+            placed[j] = (start, 1 + q)
             for k in consumers[j]:
-                ready_at[k] = max(ready_at[k], t1)
+                ready_at[k] = max(ready_at[k], clock[q])
                 indeg[k] -= 1
                 if indeg[k] == 0:
-                    heapq.heappush(heap, (ready_at[k], k))
-        return max(fin0[s - 1], t1), starts
+                    heapq.heappush(heaps[which(k)], (ready_at[k], k))
+        return max(fin0[s - 1], clock[0], clock[1]), placed
 
-    best_s, best, best_starts = 0, serial, None
+    best_s, best, best_placed = 0, serial, None
     for s in range(1, n):
-        span, starts = simulate(s)
-        if span < best:
-            best_s, best, best_starts = s, span, starts
+        span, placed = simulate(s, bound=best)
+        if placed is not None and span < best:
+            best_s, best, best_placed = s, span, placed
     if best_s == 0 or best > 0.95 * serial:
         return stream, order
+    if nstreams >= 3:
+        s = best_s
+        for x in range(s, n):
+            chain, stack = {x}, [x]
+            while stack:
+                for k in consumers[stack.pop()]:
+                    if k not in chain:
+                        chain.add(k)
+                        stack.append(k)
+            if len(chain) < 8 or len(chain) > (n - s) - 8:
+                continue
+            span, placed = simulate(s, chain, bound=best)
+            if placed is not None and span < 0.97 * best:
+                best, best_placed = span, placed
     start = [fin0[i] - cost[i] for i in range(n)]
-    for st_, j in best_starts:
+    for j, (st_, q) in best_placed.items():
         start[j] = st_
-        stream[j] = 1
+        stream[j] = q
     # merged launch order: by simulated start time (a step starts after everything it reads has finished, costs are
     # positive: the order is topological); stream-0 steps keep their relative order
     order = sorted(range(n), key=lambda j: (start[j], j))
@@ -262,7 +290,7 @@ def finalize(plan, nstreams=1, policy='list'):
     streams, latency regime)."""
     deps = compute_deps(plan)
     if policy == 'tail' and nstreams >= 2:
-        stream, order = assign_streams_tail(plan, deps)
+        stream, order = assign_streams_tail(plan, deps, nstreams=nstreams)
         if order != list(range(len(order))):
             plan.steps[:] = [plan.steps[j] for j in order]
             deps = compute_deps(plan)
