@@ -480,9 +480,10 @@ def test_conv2d_uint8_frames_normalised_on_load(k, s, cout, power, hip_lib, cuda
 
 @pytest.mark.gpu
 @pytest.mark.parametrize('case', [
-    (2, 33, 31, 32, 64, 3, 3, 1, 'same'), (1, 32, 32, 64, 96, 3, 3, 2, 'same'), (2, 20, 24, 64, 64, 5, 1, 1, 'same'),
-    (2, 20, 24, 64, 64, 1, 5, 1, 'same'), (1, 12, 12, 32, 32, 3, 3, 1, 'valid'), (2, 17, 19, 96, 72, 5, 5, 2, 'same'),
-    (1, 16, 16, 192, 192, 3, 3, 2, 'same'), (2, 9, 9, 160, 64, 1, 1, 2, 'same')])
+    # (every output map has more than 256 positions: smaller ones belong to the skinny-conv kernel by rule [r05])
+    (2, 33, 31, 32, 64, 3, 3, 1, 'same'), (1, 40, 40, 64, 96, 3, 3, 2, 'same'), (2, 20, 24, 64, 64, 5, 1, 1, 'same'),
+    (2, 20, 24, 64, 64, 1, 5, 1, 'same'), (1, 20, 20, 32, 32, 3, 3, 1, 'valid'), (2, 35, 37, 96, 72, 5, 5, 2, 'same'),
+    (1, 34, 34, 192, 192, 3, 3, 2, 'same'), (2, 33, 33, 160, 64, 1, 1, 2, 'same')])
 @pytest.mark.parametrize('cfg', [9, 11, 12, 13, 15, 17])
 def test_kxk_conv_on_the_dma_kernel(case, cfg, hip_lib, cuda):
     """K x K / strided / TF-SAME convolutions with Cin % 32 == 0 on the LDS-DMA kernel (taps in the zero padding
@@ -647,13 +648,13 @@ SPLIT_CASES = [
     (2, 32, 32, 48, 576, 1, 1, True, False, False),      # fReMap: K = 48 (padded to 64)
     (2, 16, 16, 288, 576, 1, 1, False, True, True),      # fused up-sampling epilogue
     (2, 33, 31, 64, 96, 3, 1, True, False, False),       # K x K through the zero-page DMA, ragged M
-    (1, 32, 32, 64, 96, 3, 2, False, False, False),      # strided
+    (1, 32, 32, 64, 288, 3, 2, False, False, False),     # strided (288 output channels: a 16 x 16 map with <= 256 is skinny)
     (2, 19, 23, 96, 200, 1, 1, True, True, False),       # ragged everywhere
 ]
 
 
 @pytest.mark.parametrize('case', [(3, 32, 32, 96, 200, 1, True, True, False), (2, 32, 32, 48, 576, 1, True, False, True),
-                                  (2, 64, 64, 64, 96, 3, False, True, False), (1, 6, 32, 288, 96, 1, False, False, False),
+                                  (2, 64, 64, 64, 96, 3, False, True, False), (1, 6, 32, 288, 288, 1, False, False, False),
                                   (2, 32, 32, 64, 100, 3, True, True, False)])
 def test_conv2d_pooled_second_output(case, hip_lib, cuda):
     """dh_conv_args.y_pool: the epilogue also writes MaxPooling2D((2, 2)) of the final output.  Equal to pooling the

@@ -541,3 +541,13 @@ def test_integration_guide_declares_the_whole_conv_struct():
     block = doc[doc.index('class ConvArgs(C.Structure)'):doc.index('lib.dh_conv2d_f32.argtypes')]
     names = re.findall(r"'([A-Za-z_0-9]+)'", block)
     assert names == [n for n, _ in _lib.ConvArgs._fields_]
+
+
+def test_design_tables_are_generated_from_the_tracked_records():
+    """DESIGN.md's tables of current-round numbers (parity worst cases, workloads, the speed protocol)
+    are generated from profiles/*.json by tools/design_tables.py; a hand edit or a stale record fails here."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, 'tools', 'design_tables.py'), '--check'], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
