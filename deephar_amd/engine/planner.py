@@ -74,6 +74,29 @@ def split_k_rule(out_pixels, K, cout, cin):
     return out_pixels <= 256 and K >= 64 and cout <= 256 and 2 <= cin <= 4096
 
 
+class ConcatParam:
+    """Several convolution kernels with equal [kh, kw, Cin] side by side along Cout: the weight a horizontally merged
+    convolution (rule R10) reads.  Looks like a graph.Param to the weight store: `value` is assembled on demand, `version`
+    moves whenever a part is set."""
+    role = 'conv'
+
+    def __init__(self, parts):
+        self.parts = list(parts)
+        self.key = ' + '.join(p.key for p in self.parts)
+        self.name = 'kernel'
+        self.shape = tuple(self.parts[0].shape[:-1]) + (sum(p.shape[-1] for p in self.parts),)
+
+    @property
+    def value(self):
+        if any(p.value is None for p in self.parts):
+            return None
+        return np.ascontiguousarray(np.concatenate([p.value for p in self.parts], axis=-1))
+
+    @property
+    def version(self):
+        return sum(p.version for p in self.parts)
+
+
 class Step:
     def __init__(self, kind, ins, outs, attrs=None, params=None, name=None):
         self.stream, self.deps, self.wait, self.record = 0, [], [], False   # filled by schedule.finalize
@@ -270,10 +293,28 @@ class Planner:
     def lazy_or_value(self, t):
         return self.val[t.uid]
 
+    # consumers that read a tensor through a (pointer, pixel pitch) view whatever its pitch: they may share a producer's
+    # output with ONE concatenate, which then needs no copy (R4b)
+    _VIEW_READERS = ('softmax2d', 'jointprob', 'globalmax2d', 'conv')
+
+    def _concat_home(self, t):
+        """The concatenate whose buffer t's producer writes into (R4): t's only consumer -- or [r05, R4b] the only
+        concatenate among consumers that all read strided views.  SPNet's heat-map head (spnet.py:24-48): `pred_maps` goes
+        to the channel soft-max AND into concatenate([fw_maps, pred_maps]); written where the concatenation wants it, the
+        soft-argmax kernel reads it there (pitch 2 J) and the copy launch disappears.  DEEPHAR_CONCAT_SHARED=0: off."""
+        cat = self.sole_consumer(t, 'concat')
+        if cat is not None or self.out_uids.get(t.uid, 0) or os.environ.get('DEEPHAR_CONCAT_SHARED', '1') == '0':
+            return cat
+        cs = [n for n, _ in self.consumers.get(t.uid, [])]
+        cats = [n for n in cs if n.op == 'concat']
+        if len(cats) != 1 or any(n.op not in self._VIEW_READERS for n in cs if n.op != 'concat'):
+            return None
+        return cats[0]
+
     def out_value_for(self, t, shape=None):
         """Where the producer of t should write: inside a concat buffer if t's only consumer is a concat."""
         shape = shape or t.shape
-        cat = self.sole_consumer(t, 'concat')
+        cat = self._concat_home(t)
         if cat is not None and all(len(x.shape) == len(shape) for x in cat.inputs):
             cv = self.concat_val.get(cat.uid)
             if cv is None:
@@ -309,10 +350,70 @@ class Planner:
             v = self.materialize(t)
             v.buf.pinned = True
             self.plan.outputs.append(v)
+        self._merge_sibling_pointwise()
         self._collect_params()
         from . import schedule
         schedule.finalize(self.plan, self.nstreams, self.stream_policy)
         return self.plan
+
+    # ---- R10: sibling 1x1 convolutions that fill neighbouring channel slabs of one buffer ------------------------
+    def _merge_sibling_pointwise(self):
+        """[r05] SPNet's heat-map head (spnet.py:24-48): `_fw_maps` and `_conv1` are two 1x1 convolutions of the SAME activated
+        tensor, num_joints columns each, concatenated right away -- R4 already makes them write neighbouring channel slabs of
+        the concatenation buffer.  They become ONE launch over both weight matrices side by side: 16 + 16 (17 + 17) columns
+        are one 32-column tile (two 16-column tiles on the skinny kernel), each output column keeps its own K order, so the
+        result is bit-identical and a launch is saved per prediction block.  (Round 4 tried the same on the 64 -> 96 | 48
+        pairs of the entry flow -- widths that tile worse together than apart; this rule only merges slabs that stay
+        inside the family rule of their parts and carry no epilogue.)  DEEPHAR_MERGE_HEADS=0 switches it off."""
+        if os.environ.get('DEEPHAR_MERGE_HEADS', '1') == '0':
+            return
+        same = ('kh', 'kw', 'sh', 'sw', 'pt', 'pl', 'Cin', 'K', 'pre_relu', 'post_relu', 'up2', 'res2_down')
+
+        def mergeable(a, b):
+            if a.kind != 'conv' or b.kind != 'conv' or set(a.ins) != {'x'} or set(b.ins) != {'x'} or \
+                    set(a.outs) != {'y'} or set(b.outs) != {'y'}:
+                return False
+            if any(a.attrs.get(k) != b.attrs.get(k) for k in same) or a.attrs['kh'] != 1 or a.attrs['kw'] != 1 or \
+                    a.attrs['up2'] or a.attrs['res2_down'] or a.attrs.get('sh', 1) != 1 or a.attrs.get('sw', 1) != 1:
+                return False
+            if set(a.params) - {'w', 'pre_bn'} or set(b.params) - {'w', 'pre_bn'} or \
+                    a.params.get('pre_bn') is not b.params.get('pre_bn'):
+                return False
+            xa, xb, ya, yb = a.ins['x'], b.ins['x'], a.outs['y'], b.outs['y']
+            if xa.buf is not xb.buf or (xa.coff, xa.ld, xa.shape) != (xb.coff, xb.ld, xb.shape):
+                return False
+            if ya.buf is not yb.buf or ya.ld != yb.ld or ya.shape[:-1] != yb.shape[:-1] or ya.coff + ya.C != yb.coff:
+                return False
+            px = ya.shape[-3] * ya.shape[-2] if len(ya.shape) >= 3 else 1
+            fam = lambda c: split_k_rule(px, a.attrs['K'], c, a.attrs['Cin'])
+            return fam(ya.C) == fam(yb.C) == fam(ya.C + yb.C)
+
+        steps = self.plan.steps
+        i = 0
+        while i + 1 < len(steps):
+            a = steps[i]
+            # the sibling may sit a few steps further down (the soft-argmax read-out of the first head is emitted between
+            # them): it only reads x, which exists before a, and buffers are still logical here (no re-use yet), so it can
+            # be pulled up to a's place
+            j = next((j for j in range(i + 1, min(i + 8, len(steps))) if mergeable(a, steps[j]) or mergeable(steps[j], a)), None)
+            if j is None:
+                i += 1
+                continue
+            b = steps[j]
+            first, second = (a, b) if mergeable(a, b) else (b, a)
+            ya, yb = first.outs['y'], second.outs['y']
+            y = Value(ya.shape[:-1] + (ya.C + yb.C,), ya.buf, ya.coff, ya.ld)
+            parts = []
+            for st in (first, second):
+                w = st.params['w']
+                parts += w.parts if isinstance(w, ConcatParam) else [w]
+            params = dict(first.params, w=ConcatParam(parts))
+            attrs = dict(first.attrs, Cout=ya.C + yb.C)
+            merged = Step('conv', dict(first.ins), dict(y=y), attrs, params, '%s+%s' % (first.name, second.name))
+            del steps[j]
+            steps[i] = merged
+            for v in (ya, yb, y):
+                self.producer[id(v)] = merged
 
     # ---- R3: add([a, UpSampling2D(b)]) as the second residual of the convolution that produces a --------------
     def _upsampled_residual(self, t):

@@ -160,6 +160,34 @@ def test_multi_stream_plans_are_bit_identical(hip_lib, cuda):
             assert np.array_equal(a, b)
 
 
+def test_heat_map_head_rules_are_bit_identical(hip_lib, cuda, monkeypatch):
+    """[r05] Planner rules R4b (`pred_maps` written straight into the slab of concatenate([fw_maps, pred_maps]) although the
+    channel soft-max reads it too: spnet.py:24-48) and R10 (`_fw_maps` and `_conv1`, two 1x1 convolutions of one tensor into
+    neighbouring slabs, as ONE launch over both weight matrices): fewer launches, not one bit moved -- 2-D and 3-D SPNet,
+    with and without the replica head; weights changed after the first predict reach the merged launch."""
+    from deephar_amd import weights
+    for layout, nact, rep in (('pa16j2d', 15, True), ('pa17j3d', 60, False)):
+        clips = np.random.default_rng(21).uniform(-1, 1, (2, 4, 128, 128, 3)).astype(np.float32)
+        monkeypatch.setenv('DEEPHAR_MERGE_HEADS', '0')
+        monkeypatch.setenv('DEEPHAR_CONCAT_SHARED', '0')
+        base, _, _, _ = _spnet(4, layout, nact, 2, [1, 2], 160, replica=rep, res=128)
+        want = base.predict(clips, batch_size=2)
+        nbase = len(base.plan.steps)
+        monkeypatch.setenv('DEEPHAR_MERGE_HEADS', '1')
+        monkeypatch.setenv('DEEPHAR_CONCAT_SHARED', '1')
+        m, _, _, _ = _spnet(4, layout, nact, 2, [1, 2], 160, replica=rep, res=128)
+        merged = [s for s in m.plan.steps if s.kind == 'conv' and '+' in (s.name or '')]
+        assert len(merged) == 5 and len(m.plan.steps) == nbase - 10          # five heads: one copy and one conv less each
+        for a, b in zip(want, m.predict(clips, batch_size=2)):
+            assert np.array_equal(a, b)
+        # a weight of ONE part changed after the first predict: the merged launch must see it
+        layer = next(l for n in m._nodes for l in n.layers.values() if l.name.endswith('pb1_heatmaps_fw_maps'))
+        layer.params[0].set(0.5 * layer.params[0].value)
+        next(l for n in base._nodes for l in n.layers.values() if l.name == layer.name).params[0].set(layer.params[0].value)
+        for a, b in zip(base.predict(clips, batch_size=2), m.predict(clips, batch_size=2)):
+            assert np.array_equal(a, b)
+
+
 def test_predict_accepts_float64_and_partial_batches(hip_lib, cuda):
     m, _ = _build(2, 1, 16, num_context_per_joint=2)
     x = np.random.default_rng(6).uniform(-1, 1, (5, 256, 256, 3))     # float64, like loader.py:139-140
@@ -234,7 +262,7 @@ def test_merge_action_model_parity(pose_dim, joints, version, hip_lib, cuda):
         np.testing.assert_allclose(hip[k].sum(-1), 1.0, rtol=1e-5)
 
 
-def _spnet(T, layout, num_actions, pyramids, action_pyramids, feats, replica=False, calibrate=None):
+def _spnet(T, layout, num_actions, pyramids, action_pyramids, feats, replica=False, calibrate=None, res=256):
     """calibrate: frames [N, T, 256, 256, 3] -> heat-map heads are brought to logit std ~ 6 before the weights are
     read out (paritylog.calibrate_spnet_heads)."""
     from deephar_amd import graph, weights, utils
@@ -242,7 +270,7 @@ def _spnet(T, layout, num_actions, pyramids, action_pyramids, feats, replica=Fal
     from deephar_amd.models import spnet
     graph.reset_naming()
     lay = getattr(utils, layout)
-    cfg = ModelConfig((T, 256, 256, 3), lay, num_actions=[num_actions], num_pyramids=pyramids,
+    cfg = ModelConfig((T, res, res, 3), lay, num_actions=[num_actions], num_pyramids=pyramids,
                       action_pyramids=action_pyramids, num_levels=4, pose_replica=replica, num_pose_features=feats,
                       num_visual_features=feats)
     m = spnet.build(cfg)
