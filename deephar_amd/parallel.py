@@ -194,6 +194,7 @@ class ShardedClipModel:
         for stage in (self.frame_model, self.head_model):          # the stages run with the clip model's engine options
             if stage is not None:
                 stage.num_streams, stage.gemm_precision = model.num_streams, model.gemm_precision
+                stage.stream_policy = model.stream_policy
         self.frame_fn = frame_fn or self._frame_hip
         self.head_fn = head_fn or self._head_hip
         self.last_outputs = None

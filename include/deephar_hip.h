@@ -107,8 +107,13 @@ int dh_conv2d_pack_weights_split_host(const float* w_hwio_host, uint16_t* packed
 int dh_conv2d_num_tile_cfgs(void);
 int dh_conv2d_num_split_tile_cfgs(void); /* tilings of the w_split = 1 kernels: tile_cfg in [0, this) */
 int dh_conv2d_pick_tile_cfg(int M, int Cout);
-/* 1 when dh_conv2d_f32 runs this convolution on the in-work-group split-K kernel (tiny per-frame output, long
- * reduction: the action heads, deephar/models/blocks.py action_top / build_act_pred_block): a rule on OH*OW, K, Cout and
+/* Inputs must be FINITE.  K is padded to the kernels' step with zero weights, and on the LDS-DMA GEMM a padded k slot of
+ * a pixel holds the following floats in memory (the next pixel's first channels, clamped inside the buffer): an Inf / NaN
+ * there would reach this pixel's output as 0 * Inf.  The first-layer kernel (raw frames) and the skinny-conv
+ * kernel zero the padded A operand instead; activations inside a model are finite by construction. */
+/* 1 when dh_conv2d_f32 runs this convolution on the skinny-conv kernel (conv_splitk.hip: a tiny output map -- at most 256
+ * positions per frame / clip, at most 256 output channels, K >= 64 [r05; was K >= 768, Cin % 4 == 0]: the action heads,
+ * deephar/models/spnet.py:51-148, action.py:20-42, and the coarse heat-map heads, spnet.py:24-48): a rule on OH*OW, K, Cout and
  * Cin only, so that a layer's result bits never depend on tiling choice, batch size or alignment.  Such a layer takes
  * fp32-packed weights (w_split = 0) and ignores tile_cfg. */
 int dh_conv2d_uses_split_k(const dh_conv_args* a);

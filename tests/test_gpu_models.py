@@ -188,6 +188,33 @@ def test_heat_map_head_rules_are_bit_identical(hip_lib, cuda, monkeypatch):
             assert np.array_equal(a, b)
 
 
+def test_speed_protocol_truncated_models(hip_lib, cuda):
+    """exp/pennaction/eval_speed2d.py:60-68: `Model(full_model.input, full_model.outputs[2*b:2*b+2])` for every prediction
+    block b, each with one warm-up `predict(x[0:1])` and then `predict(x, batch_size=2)`.  On a reduced configuration (two
+    pyramids, 128 px; actions on both, pose_replica): every truncated model returns exactly the two outputs of the full
+    model it was cut from -- bit for bit, also with the latency-regime engine setting (two streams, 'tail' policy), and the
+    plan of a pose-only truncation holds no action-stream launch."""
+    from deephar_amd import Model
+    full, _, _, _ = _spnet(8, 'pa16j2d', 15, 2, [1, 2], 160, replica=True, res=128)
+    x = np.random.default_rng(23).uniform(-1, 1, (4, 8, 128, 128, 3)).astype(np.float32)
+    want = full.predict(x, batch_size=2)
+    nb = len(full.outputs) // 2
+    assert nb == 6 and len(want) == 12
+    for b in range(nb):
+        for streams, policy in ((1, 'list'), (2, 'tail')):
+            m = Model(full.input, full.outputs[2 * b:2 * b + 2])
+            m.num_streams, m.stream_policy = streams, policy
+            m.predict(x[0:1])                                        # "Warming up the new model."
+            got = m.predict(x, batch_size=2)
+            assert len(got) == 2
+            for a, w in zip(got, want[2 * b:2 * b + 2]):
+                assert a.shape == w.shape and np.array_equal(a, w), (b, streams)
+            if b < nb // 2:                                          # outputs 2b, 2b + 1 are poses: no action head needed
+                assert not any('action' in (s.name or '') for s in m.plan.steps)
+            if streams == 2 and b == nb - 1:
+                assert m.plan.nstreams == 2
+
+
 def test_predict_accepts_float64_and_partial_batches(hip_lib, cuda):
     m, _ = _build(2, 1, 16, num_context_per_joint=2)
     x = np.random.default_rng(6).uniform(-1, 1, (5, 256, 256, 3))     # float64, like loader.py:139-140
