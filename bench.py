@@ -251,8 +251,6 @@ def kernel_name(s):
             return 'gemm1x1s_wide_kernel<%d, %s, %s, %s>' % (SPLIT_WIDE[cfg], b(a['up2']), b(a['pre_relu']), b(kxk))
         t, ns = SPLIT_TILES[cfg]
         return 'gemm1x1s_kernel<%d, %d, %d, %d, %s, %s, %s, %d>' % (t + (b(a['up2']), b(a['pre_relu']), b(kxk), ns))
-    if cfg == 18:
-        return 'gemm1x1_fine_kernel<%s, %s>' % (b(a['pre_relu']), b('pre_bn' in s.params))
     t = TILES[cfg % 9]
     if cfg >= 9:
         kxk = not (a['kh'] == a['kw'] == 1 and a['sh'] == a['sw'] == 1 and a['pt'] == a['pl'] == 0)

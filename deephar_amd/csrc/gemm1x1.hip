@@ -336,8 +336,6 @@ int launch_cfg(const ConvArgs& a, int epi, hipStream_t s) {
 
 }  // namespace
 
-int launch_gemm1x1_fine(const ConvArgs& a, hipStream_t s);
-
 bool gemm1x1_eligible(const ConvArgs& a) {
   const bool aligned = a.ldx % 4 == 0 && (reinterpret_cast<uintptr_t>(a.x) & 15) == 0 &&
                        (reinterpret_cast<uintptr_t>(a.w) & 15) == 0;
@@ -365,11 +363,10 @@ int launch_gemm1x1(const ConvArgs& a, int cfg, int epi, hipStream_t s) {
     case 6: return launch_cfg<2, 1, 1, 2>(a, epi, s);
     case 7: return launch_cfg<2, 1, 1, 1>(a, epi, s);
     case 8: return launch_cfg<1, 1, 1, 1>(a, epi, s);
-    case 9: return launch_gemm1x1_fine(a, s);      // 16 x 16 tiles, same K order (gemm1x1f.hip): small launches
   }
   return DH_EINVAL;
 }
 
-int gemm1x1_num_cfgs() { return 10; }
+int gemm1x1_num_cfgs() { return 9; }
 
 }  // namespace dh
