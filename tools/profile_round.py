@@ -119,7 +119,7 @@ def main():
     ap.add_argument('--skip-pmc', action='store_true')
     ap.add_argument('--skip-stats', action='store_true')
     ap.add_argument('--steps', type=int, default=20)
-    ap.add_argument('--all-tilings', default='mpii',
+    ap.add_argument('--all-tilings', default='mpii,h36m',
                     help='workloads whose dominant GEMM is PMC-profiled on all three <4,1,1,N> tilings (2 passes each)')
     args = ap.parse_args()
     os.makedirs(OUT, exist_ok=True)
