@@ -443,7 +443,7 @@ def setup_clips(workload, model, per_gpu, world, rank, args, load_tune=None, sav
     wl = WORKLOADS[workload]
     T = wl['T']
     clips = per_gpu * world
-    scm = parallel.ShardedClipModel(model, rank=rank, world=world)
+    scm = parallel.ShardedClipModel(model, rank=rank, world=world, always_collective=bool(getattr(args, 'force_collective', False)))
     fm, hm, info = scm.frame_model, scm.head_model, scm.info
     for mm in (fm, hm):
         mm.executor.use_graph = not args.no_graph
@@ -614,6 +614,9 @@ def main():
     ap.add_argument('--tune-cache', default=None,
                     help='JSON file with the autotuned conv tilings: loaded if present (no tuning launches, '
                          'keeps rocprofv3 kernel stats clean), written otherwise')
+    ap.add_argument('--force-collective', action='store_true',
+                    help='clip workloads at N = 1: issue the RCCL all_gather_into_tensor anyway (a world of one would '
+                         'short-cut to a view) -- `collective_us` is then the cost of the RCCL call path on one GPU')
     ap.add_argument('--dry-run', action='store_true',
                     help='launcher / rendezvous / all-gather / JSON contract on the gloo backend, no HIP device')
     ap.add_argument('--replay-step', type=int, default=None,
@@ -648,8 +651,10 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs a HIP device (the product path has no CPU fallback)')
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    if world > 1 or args.force_collective:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        if world == 1:
+            os.environ.setdefault('MASTER_PORT', str(_free_port()))
         dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local_rank))
 
     def barrier():
@@ -863,6 +868,7 @@ def main():
         if collective_us is not None:
             out['collective_us'] = collective_us
             out['rccl_ranks'] = world
+            out['collective_forced_at_world_1'] = bool(world == 1 and args.force_collective)
         if clip_leg is not None:
             out['frame_sharded_clips'] = clip_leg
         if split_leg is not None:
@@ -886,6 +892,7 @@ def main():
         print(json.dumps(out))
     if world > 1:
         dist.barrier()
+    if world > 1 or args.force_collective:
         dist.destroy_process_group()
 
 
