@@ -260,3 +260,41 @@ def test_layer_semantics_against_independent_numpy_loops(h, w, k, s):
     np.testing.assert_allclose(O.batchnorm(t(x), t(beta), t(mean), t(var), gamma=t(gamma)).numpy(), bn, atol=1e-12)
     bn0 = (x - mean) / np.sqrt(var + 1e-3) + beta                         # layers.py BatchNormalization(scale=False)
     np.testing.assert_allclose(O.batchnorm(t(x), t(beta), t(mean), t(var)).numpy(), bn0, atol=1e-12)
+
+
+@pytest.mark.parametrize('h,w', [(256, 256), (128, 128), (33, 31), (17, 20), (8, 16)])
+@pytest.mark.parametrize('k,s', [(1, 1), (3, 1), (3, 2), (5, 1), (5, 2), (7, 2), (2, 2)])
+def test_same_padding_against_a_third_party_statement(h, w, k, s):
+    """[r05] One more witness for the Keras / TF semantics this oracle restates ("Keras-layer numerics restated
+    by the same author in every witness"): `apply_tf_padding` of HuggingFace transformers' MobileNetV2 port -- written by
+    others to reproduce TensorFlow checkpoints bit for bit, so TF's 'SAME' rule (pad_total from in % stride, the extra pixel
+    on the bottom / right) is stated there independently.  The oracle's Conv2D / depthwise convolution on every geometry
+    the models use (kernels 1-7, strides 1-2, even and odd maps) equals torch's convolution behind that padding, and the
+    product's own `layers.same_pad` (which fills dh_conv_args.PT / PL) names the same pixels."""
+    tf_pad = pytest.importorskip('transformers.models.mobilenet_v2.modeling_mobilenet_v2').apply_tf_padding
+    from deephar_amd.layers import same_pad
+    rng = np.random.default_rng(h * 131 + w * 7 + k * 3 + s)
+    cin, cout = 3, 4
+    x = torch.from_numpy(rng.standard_normal((2, h, w, cin)))
+    kern = torch.from_numpy(rng.standard_normal((k, k, cin, cout)))
+    conv = torch.nn.Conv2d(cin, cout, k, stride=s, bias=False).double()
+    with torch.no_grad():
+        conv.weight.copy_(kern.permute(3, 2, 0, 1))
+        want = conv(tf_pad(x.permute(0, 3, 1, 2), conv)).permute(0, 2, 3, 1)
+    got = ops.conv2d(x, kern, (s, s), 'same')
+    assert got.shape == want.shape == (2, -(-h // s), -(-w // s), cout)
+    assert torch.allclose(got, want, rtol=0, atol=1e-12)
+    # the depthwise half of SeparableConv2D goes through the same rule
+    dwk = torch.from_numpy(rng.standard_normal((k, k, cin, 1)))
+    dconv = torch.nn.Conv2d(cin, cin, k, stride=s, groups=cin, bias=False).double()
+    with torch.no_grad():
+        dconv.weight.copy_(dwk.permute(2, 3, 0, 1))
+        dwant = dconv(tf_pad(x.permute(0, 3, 1, 2), dconv)).permute(0, 2, 3, 1)
+    assert torch.allclose(ops.depthwise_conv2d(x, dwk, (s, s), 'same'), dwant, rtol=0, atol=1e-12)
+    # the host-side rule of the product: pixels of padding before each axis = what the third-party statement pads
+    padded = tf_pad(torch.zeros(1, 1, h, w), conv)
+    pt, pb, oh = same_pad(h, k, s)
+    pl, pr, ow = same_pad(w, k, s)
+    assert (padded.shape[-2], padded.shape[-1]) == (h + pt + pb, w + pl + pr) and (oh, ow) == tuple(want.shape[1:3])
+    probe = tf_pad(torch.ones(1, 1, h, w), conv)[0, 0]
+    assert bool((probe[:pt] == 0).all()) and bool((probe[:, :pl] == 0).all()) and probe[pt, pl] == 1
