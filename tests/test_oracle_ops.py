@@ -298,3 +298,21 @@ def test_same_padding_against_a_third_party_statement(h, w, k, s):
     assert (padded.shape[-2], padded.shape[-1]) == (h + pt + pb, w + pl + pr) and (oh, ow) == tuple(want.shape[1:3])
     probe = tf_pad(torch.ones(1, 1, h, w), conv)[0, 0]
     assert bool((probe[:pt] == 0).all()) and bool((probe[:, :pl] == 0).all()) and probe[pt, pl] == 1
+
+
+@pytest.mark.parametrize('h,w', [(128, 128), (33, 31), (17, 20), (8, 16), (5, 5)])
+@pytest.mark.parametrize('k,s', [(3, 2), (2, 2), (3, 1)])
+def test_same_max_pooling_geometry_against_a_third_party_statement(h, w, k, s):
+    """[r05] `layers.maxpooling2d` = MaxPooling2D((3, 3), strides 2, 'same') (layers.py:92-97) and `max_min_pooling`
+    (layers.py:411-425): the window geometry of TF 'SAME' pooling as HuggingFace transformers' BiT port states it
+    (`BitMaxPool2d` + `DynamicPad2d`: a ceil-based formula written to reproduce TF checkpoints), with the padding value this
+    oracle states itself (TF ignores padded cells: -inf).  All-negative inputs, so a zero-padded pool would differ."""
+    bit = pytest.importorskip('transformers.models.bit.modeling_bit')
+    rng = np.random.default_rng(h * 17 + w + k + s)
+    x = -torch.from_numpy(rng.random((2, h, w, 5))) - 0.5
+    pool = bit.BitMaxPool2d(k, stride=s, padding_value=float('-inf'))
+    want = pool(x.permute(0, 3, 1, 2)).permute(0, 2, 3, 1)
+    got = ops.maxpool2d(x, (k, k), (s, s), 'same')
+    assert got.shape == want.shape == (2, -(-h // s), -(-w // s), 5) and torch.equal(got, want)
+    assert float(got.max()) < 0 and not torch.equal(got, bit.BitMaxPool2d(k, stride=s)(x.permute(0, 3, 1, 2)).permute(0, 2, 3, 1)) \
+        or (h % s == 0 and w % s == 0 and k <= s)
