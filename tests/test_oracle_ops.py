@@ -316,3 +316,20 @@ def test_same_max_pooling_geometry_against_a_third_party_statement(h, w, k, s):
     assert got.shape == want.shape == (2, -(-h // s), -(-w // s), 5) and torch.equal(got, want)
     assert float(got.max()) < 0 and not torch.equal(got, bit.BitMaxPool2d(k, stride=s)(x.permute(0, 3, 1, 2)).permute(0, 2, 3, 1)) \
         or (h % s == 0 and w % s == 0 and k <= s)
+
+
+def test_upsampling_and_batchnorm_against_torch_kernels():
+    """[r05] UpSampling2D (nearest) and inference BatchNormalization (epsilon inside the square root, `scale=False` layers
+    have no gamma) against torch's own kernels -- third-party code for the formula; Keras' default epsilon 1e-3
+    (`deephar/layers.py:51-58` passes none) remains this oracle's statement."""
+    import torch.nn.functional as F
+    rng = np.random.default_rng(5)
+    x = torch.from_numpy(rng.standard_normal((2, 5, 7, 6)))
+    up = F.interpolate(x.permute(0, 3, 1, 2), scale_factor=2, mode='nearest').permute(0, 2, 3, 1)
+    assert torch.equal(ops.upsample2d(x, (2, 2)), up)
+    mean, var = torch.from_numpy(rng.standard_normal(6)), torch.from_numpy(rng.random(6) + 0.5)
+    beta, gamma = torch.from_numpy(rng.standard_normal(6)), torch.from_numpy(rng.random(6) + 0.5)
+    for g in (None, gamma):
+        want = F.batch_norm(x.permute(0, 3, 1, 2), mean, var, weight=g, bias=beta, training=False, eps=1e-3).permute(0, 2, 3, 1)
+        got = ops.batchnorm(x, beta, mean, var, g)
+        assert torch.allclose(got, want, rtol=0, atol=1e-12)
