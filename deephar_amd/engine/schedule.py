@@ -173,26 +173,37 @@ def assign_streams_tail(plan, deps, items=2, nstreams=2):
         return max(fin0[s - 1], clock[0], clock[1]), placed
 
     best_s, best, best_placed = 0, serial, None
+    spans = {}
     for s in range(1, n):
-        span, placed = simulate(s, bound=best)
-        if placed is not None and span < best:
+        span, placed = simulate(s)
+        spans[s] = span
+        if span < best:
             best_s, best, best_placed = s, span, placed
     if best_s == 0 or best > 0.95 * serial:
         return stream, order
     if nstreams >= 3:
-        s = best_s
-        for x in range(s, n):
-            chain, stack = {x}, [x]
-            while stack:
-                for k in consumers[stack.pop()]:
-                    if k not in chain:
-                        chain.add(k)
-                        stack.append(k)
-            if len(chain) < 8 or len(chain) > (n - s) - 8:
-                continue
-            span, placed = simulate(s, chain, bound=best)
-            if placed is not None and span < 0.97 * best:
-                best, best_placed = span, placed
+        # the chain / front-end split is searched jointly with the suffix start: the best two-stream suffix keeps some of
+        # the suffix's early steps on stream 0 to balance TWO streams, which is not where three streams balance
+        descendants = {}
+
+        def cone(x):
+            if x not in descendants:
+                chain, stack = {x}, [x]
+                while stack:
+                    for k in consumers[stack.pop()]:
+                        if k not in chain:
+                            chain.add(k)
+                            stack.append(k)
+                descendants[x] = chain
+            return descendants[x]
+        for s in sorted(spans, key=spans.get)[:24]:
+            for x in range(s, n):
+                chain = cone(x)
+                if len(chain) < 8 or len(chain) > (n - s) - 8:
+                    continue
+                span, placed = simulate(s, chain, bound=best)
+                if placed is not None and span < 0.97 * best:
+                    best, best_placed = span, placed
     start = [fin0[i] - cost[i] for i in range(n)]
     for j, (st_, q) in best_placed.items():
         start[j] = st_
