@@ -551,3 +551,64 @@ def test_design_tables_are_generated_from_the_tracked_records():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, os.path.join(root, 'tools', 'design_tables.py'), '--check'], capture_output=True, text=True)
     assert r.returncode == 0, r.stdout + r.stderr
+
+
+def test_heat_map_head_rules_on_the_host(monkeypatch):
+    """[r05] Planner rules R4b / R10 without a GPU: on SPNet's heat-map head (spnet.py:24-48) the copy into
+    concatenate([fw_maps, pred_maps]) disappears (pred_maps is written in place, the soft-argmax reads it there at pitch 2 J)
+    and `_fw_maps` + `_conv1` become ONE convolution over both kernels side by side; the merged weight follows its parts."""
+    from deephar_amd import graph, utils
+    from deephar_amd.config import ModelConfig
+    from deephar_amd.engine.planner import ConcatParam
+    from deephar_amd.models import spnet
+
+    def build():
+        graph.reset_naming()
+        cfg = ModelConfig((4, 128, 128, 3), utils.pa16j2d, num_actions=[15], num_pyramids=2, action_pyramids=[1, 2],
+                          num_levels=4, pose_replica=True, num_pose_features=160, num_visual_features=160)
+        return spnet.build(cfg)
+    monkeypatch.setenv('DEEPHAR_MERGE_HEADS', '0')
+    monkeypatch.setenv('DEEPHAR_CONCAT_SHARED', '0')
+    base = build().plan
+    monkeypatch.setenv('DEEPHAR_CONCAT_SHARED', '1')
+    shared = build().plan
+    monkeypatch.setenv('DEEPHAR_MERGE_HEADS', '1')
+    m = build()
+    plan = m.plan
+    copies = lambda p: sum(1 for s in p.steps if s.kind == 'copy')
+    assert copies(base) - copies(shared) == 5 and len(shared.steps) == len(base.steps) - 5       # five heads with forward maps
+    merged = [s for s in plan.steps if s.kind == 'conv' and isinstance(s.params['w'], ConcatParam)]
+    assert len(merged) == 5 and len(plan.steps) == len(shared.steps) - 5
+    for s in merged:
+        w, y = s.params['w'], s.outs['y']
+        assert [p.key.split('/')[-2].split('_')[-2:] for p in w.parts] == [['fw', 'maps'], ['heatmaps', 'conv1']]
+        assert s.attrs['Cout'] == 32 == y.C == y.ld and y.coff == 0 and w.shape[-1] == 32 and w.value is None
+        # the soft-argmax of pred_maps reads the second slab of the same buffer
+        sam = next(t for t in plan.steps if t.kind == 'sam' and t.ins['h'].buf is y.buf)
+        assert (sam.ins['h'].coff, sam.ins['h'].C, sam.ins['h'].ld) == (16, 16, 32)
+    from deephar_amd import weights
+    weights.init_synthetic(m, seed=0)
+    w = merged[0].params['w']
+    v0, ver = w.value, w.version
+    assert v0.shape == w.shape and np.array_equal(v0[..., :16], w.parts[0].value) and np.array_equal(v0[..., 16:], w.parts[1].value)
+    w.parts[1].set(2.0 * w.parts[1].value)
+    assert w.version == ver + 1 and np.array_equal(w.value[..., 16:], 2.0 * v0[..., 16:])
+    assert sum(s.flops() for s in plan.steps) == pytest.approx(sum(s.flops() for s in base.steps))
+
+
+def test_speed_protocol_configuration_is_the_reference_script():
+    """bench.build_speed2d = exp/pennaction/eval_speed2d.py:31-36,50: six pyramids, actions on all six, pose_replica, 8-frame
+    clips, 160 features; 18 pose + 18 action outputs, and the truncated model of block b is outputs[2b:2b+2]."""
+    import bench
+    from deephar_amd import Model
+    from deephar_amd.models import spnet
+    full = bench.build_speed2d()
+    c = bench.SPEED2D_CFG
+    assert (c['num_frames'], c['num_pyramids'], c['action_pyramids'], c['pose_replica']) == (8, 6, [1, 2, 3, 4, 5, 6], True)
+    npred = spnet.get_num_predictions(6, 4)
+    assert npred == 18 and len(full.outputs) == 2 * npred and full.inputs[0].shape == (8, 256, 256, 3)
+    assert [o.shape for o in full.outputs[:npred]] == [(8, 16, 3)] * npred and [o.shape for o in full.outputs[npred:]] == [(15,)] * npred
+    last = Model(full.input, full.outputs[2 * (npred - 1):2 * npred])
+    first = Model(full.input, full.outputs[0:2])
+    assert len(first.plan.steps) < 50 < 500 < len(last.plan.steps)
+    assert bench.WORKLOADS['speed2d']['per_gpu'] == 2 and bench.WORKLOADS['speed2d']['T'] == 8
