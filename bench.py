@@ -629,6 +629,9 @@ def main():
                          'lets the PMC passes cover the tilings the autotuner alternates between from box to box)')
     ap.add_argument('--speed2d-clips', type=int, default=250, help='speed2d: clips per timed predict (eval_speed2d.py:30)')
     ap.add_argument('--speed2d-blocks', default=None, help='speed2d: comma list of prediction blocks to time (default: all 18)')
+    ap.add_argument('--force-cfg', default=None,
+                    help="A/B aid (frame workloads): 'M,K,N:cfg' pins the tiling of every conv launch of that shape "
+                         '(bit-identical; the step time of the WHOLE forward under one tiling or another)')
     ap.add_argument('--predict-frames', type=int, default=2048,
                     help='frames per Model.predict boundary measurement (SURVEY.md 8d: >= 2 000)')
     args = ap.parse_args()
@@ -703,6 +706,15 @@ def main():
         bp = ex.bind(n, u8_norm=1 if u8 else None)
         if tune:
             save_tune([ex.tune_table])
+        if args.force_cfg:                   # A/B aid: 'M,K,N:cfg' pins the tiling of every conv launch of that shape
+            shape, cfg = args.force_cfg.split(':')
+            mkn = tuple(int(v) for v in shape.split(','))
+            for i, (fn, cargs, st) in enumerate(bp.calls):
+                if st.kind == 'conv' and not st.attrs.get('split_k') and not st.attrs.get('first_layer'):
+                    a0 = cargs[0]._obj
+                    if (a0.N * a0.OH * a0.OW, a0.K, a0.Cout) == mkn:
+                        bp.calls[i] = (fn, (cargs[0], int(cfg)), st)
+                        st.attrs['tile_cfg'] = int(cfg)
         ishape = (n,) + tuple(model.inputs[0].shape)       # [n, 256, 256, 3] frames, or [n, T, 256, 256, 3] clips (speed2d)
         if u8:
             x = np.random.default_rng(1234 + rank).integers(0, 256, ishape, dtype=np.uint8)
