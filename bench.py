@@ -473,6 +473,107 @@ def setup_clips(workload, model, per_gpu, world, rank, args, load_tune=None, sav
     return step, pairs, bound, streams, clips * T, flops, check, parallelism, (lambda: None)
 
 
+def setup_frame_workload(model, n, T, args, world, rank, load_tune=None, save_tune=None):
+    """Replicas, no collective: a batch of n items (frames, or T-frame clips) resident in HBM, plus a second resident copy
+    to re-stage from.  -> (step, bound, streams, frames per step over all ranks, flops per step, check, restage)"""
+    import torch
+    plan, ex = model.plan, model.executor
+    ex.use_graph = not args.no_graph
+    if load_tune:
+        load_tune(ex)
+    u8 = args.input == 'u8'
+    bp = ex.bind(n, u8_norm=1 if u8 else None)
+    if save_tune:
+        save_tune([ex.tune_table])
+    if args.force_cfg:                   # A/B aid: 'M,K,N:cfg' pins the tiling of every conv launch of that shape
+        shape, cfg = args.force_cfg.split(':')
+        mkn = tuple(int(v) for v in shape.split(','))
+        for i, (fn, cargs, st) in enumerate(bp.calls):
+            if st.kind == 'conv' and not st.attrs.get('split_k') and not st.attrs.get('first_layer'):
+                a0 = cargs[0]._obj
+                if (a0.N * a0.OH * a0.OW, a0.K, a0.Cout) == mkn:
+                    bp.calls[i] = (fn, (cargs[0], int(cfg)), st)
+                    st.attrs['tile_cfg'] = int(cfg)
+    ishape = (n,) + tuple(model.inputs[0].shape)       # [n, 256, 256, 3] frames, or [n, T, 256, 256, 3] clips (speed2d)
+    if u8:
+        x = np.random.default_rng(1234 + rank).integers(0, 256, ishape, dtype=np.uint8)
+    else:
+        x = np.random.default_rng(1234 + rank).uniform(-1, 1, ishape).astype(np.float32)
+    with torch.cuda.stream(ex.stream):
+        ex.set_inputs(bp, [x])           # inputs resident in HBM before the timed region
+        x_dev = torch.from_numpy(x).to(ex.device)
+    ex.stream.synchronize()
+
+    def step():
+        # the input buffer is re-used by later activations inside one forward, so every step re-stages the
+        # frames from a second HBM-resident copy (device-to-device, inside the timed region)
+        with torch.cuda.stream(ex.stream):
+            if not u8:        # (the uint8 staging buffer lives outside the arena and is never overwritten)
+                bp.tensor(plan.inputs[0]).copy_(x_dev, non_blocking=True)
+            ex.forward(bp)
+
+    def restage():
+        with torch.cuda.stream(ex.stream):
+            if not u8:
+                bp.tensor(plan.inputs[0]).copy_(x_dev)
+
+    check = lambda: bp.tensor(plan.outputs[-2]).cpu().numpy()
+    return step, [(bp, ex.stream_ptr)], [ex.stream], world * n * T, plan.total_flops(n), check, restage
+
+
+def compact_leg(workload, args, rank):
+    """[r06] A short run of ANOTHER workload appended to the default (mpii) line at N = 1, so that the driver's own
+    `python bench.py` record carries every BASELINE configuration and the reference's speed protocol, not only configs[1]
+    (VERDICT r05 missing #5): 10 timed steps after 3 warm-up steps of the same device-resident step `--workload <w>` times,
+    the per-kernel pass, and the dominant launch shape priced like `roofline` (PMC traffic joined from
+    profiles/pmc_dominant_kernel.json).  Full lines with cpu_baseline: `python bench.py --workload <w>`."""
+    import copy
+    import torch
+    wl = WORKLOADS[workload]
+    a = copy.copy(args)
+    a.input, a.force_cfg, a.force_collective = 'f32', None, False
+    full = wl['build']()
+    model = full
+    if workload == 'speed2d':
+        from deephar_amd import Model
+        a.streams, a.stream_policy = 2, 'tail'
+        nb = len(full.outputs) // 2
+        model = Model(full.input, full.outputs[2 * (nb - 1):2 * nb])
+        model.num_streams, model.stream_policy = a.streams, a.stream_policy
+    pairs = None
+    if wl['clips']:
+        step, pairs, bound, streams, frames, flops, check, par, restage = setup_clips(workload, model, wl['per_gpu'], 1, rank, a)
+    else:
+        step, bound, streams, frames, flops, check, restage = setup_frame_workload(model, wl['per_gpu'], wl['T'], a, 1, rank)
+    steps = 10
+    dt = timed(step, streams, steps, 3, 1, pairs)
+    pose = check()
+    restage()
+    rows, kinds = profile_plans(bound)
+    ms = 1e3 * dt / steps
+    roof, _ = roofline(rows, kinds, flops, ms)
+    keep = ('kernel', 'achieved', 'peak', 'unit', 'frac', 'traffic', 'traffic_over_algorithmic', 'pmc_mfma_busy_fraction',
+            'main_shape_mkn', 'main_shape_epilogue', 'main_shape_avg_launch_us', 'main_shape_launches_per_step',
+            'algorithmic_bytes_per_launch', 'share_of_step_time')
+    leg = {'workload': wl['name'], 'value': round(frames * steps / dt, 1), 'unit': 'frames/s', 'steps': steps,
+           'ms_per_step': round(ms, 3), 'frames_per_step': frames, 'launches_per_step': len(rows),
+           'streams': model.plan.nstreams if not wl['clips'] else 1,
+           'whole_forward_frac': roof['whole_forward_frac'], 'gflop_per_step': round(flops / 1e9, 1),
+           'outputs_finite_in_range': bool(np.all(np.isfinite(pose)) and pose[..., :2].min() >= 0 and pose[..., :2].max() <= 1),
+           'roofline': {k: roof[k] for k in keep if k in roof}}
+    if workload == 'speed2d' and not args.no_predict:
+        # the reference's own number for three of the eighteen prediction blocks (first pose block, last pose block, last
+        # action block), through Model.predict on host arrays like eval_speed2d.py:70-77, 100 clips instead of 250
+        a.speed2d_clips, a.speed2d_blocks = 100, '0,8,17'
+        sp = speed2d_protocol(full, a, model.executor.tune_table)
+        leg['fps_per_block'] = dict(zip(('block0', 'block8', 'block17'), sp['fps_per_block']))
+        leg['fps_per_block_note'] = 'Model.predict(x, batch_size=2) on host arrays, %d clips, second timed call' % sp['num_clips']
+        leg['launches_per_call'] = dict(zip(('block0', 'block8', 'block17'), sp['launches_per_call']))
+    del model, full, step, bound, check, restage, rows
+    torch.cuda.empty_cache()
+    return leg
+
+
 def timed(step, streams, steps, warmup, world, pairs=None):
     """W untimed steps, then exactly K steps bracketed by barrier + device synchronisation; max over ranks."""
     import torch
@@ -632,6 +733,8 @@ def main():
     ap.add_argument('--force-cfg', default=None,
                     help="A/B aid (frame workloads): 'M,K,N:cfg' pins the tiling of every conv launch of that shape "
                          '(bit-identical; the step time of the WHOLE forward under one tiling or another)')
+    ap.add_argument('--no-extra-legs', action='store_true',
+                    help='mpii at N = 1: skip the compact h36m / ntu_spnet / speed2d legs appended to the line')
     ap.add_argument('--predict-frames', type=int, default=2048,
                     help='frames per Model.predict boundary measurement (SURVEY.md 8d: >= 2 000)')
     args = ap.parse_args()
@@ -696,50 +799,10 @@ def main():
                 json.dump({json.dumps(list(k)): v for k, v in merged.items()}, f)
 
     collective_us = None
+
     def setup_frames(model, tune=True):
-        """Replicas, no collective: batch resident in HBM (plus a second resident copy to re-stage from)."""
-        plan, ex, n = model.plan, model.executor, per_gpu
-        ex.use_graph = not args.no_graph
-        if tune:
-            load_tune(ex)
-        u8 = args.input == 'u8'
-        bp = ex.bind(n, u8_norm=1 if u8 else None)
-        if tune:
-            save_tune([ex.tune_table])
-        if args.force_cfg:                   # A/B aid: 'M,K,N:cfg' pins the tiling of every conv launch of that shape
-            shape, cfg = args.force_cfg.split(':')
-            mkn = tuple(int(v) for v in shape.split(','))
-            for i, (fn, cargs, st) in enumerate(bp.calls):
-                if st.kind == 'conv' and not st.attrs.get('split_k') and not st.attrs.get('first_layer'):
-                    a0 = cargs[0]._obj
-                    if (a0.N * a0.OH * a0.OW, a0.K, a0.Cout) == mkn:
-                        bp.calls[i] = (fn, (cargs[0], int(cfg)), st)
-                        st.attrs['tile_cfg'] = int(cfg)
-        ishape = (n,) + tuple(model.inputs[0].shape)       # [n, 256, 256, 3] frames, or [n, T, 256, 256, 3] clips (speed2d)
-        if u8:
-            x = np.random.default_rng(1234 + rank).integers(0, 256, ishape, dtype=np.uint8)
-        else:
-            x = np.random.default_rng(1234 + rank).uniform(-1, 1, ishape).astype(np.float32)
-        with torch.cuda.stream(ex.stream):
-            ex.set_inputs(bp, [x])           # inputs resident in HBM before the timed region
-            x_dev = torch.from_numpy(x).to(ex.device)
-        ex.stream.synchronize()
-
-        def step():
-            # the input buffer is re-used by later activations inside one forward, so every step re-stages the
-            # frames from a second HBM-resident copy (device-to-device, inside the timed region)
-            with torch.cuda.stream(ex.stream):
-                if not u8:        # (the uint8 staging buffer lives outside the arena and is never overwritten)
-                    bp.tensor(plan.inputs[0]).copy_(x_dev, non_blocking=True)
-                ex.forward(bp)
-
-        def restage():
-            with torch.cuda.stream(ex.stream):
-                if not u8:
-                    bp.tensor(plan.inputs[0]).copy_(x_dev)
-
-        check = lambda: bp.tensor(plan.outputs[-2]).cpu().numpy()
-        return step, [(bp, ex.stream_ptr)], [ex.stream], world * n * wl['T'], plan.total_flops(n), check, restage
+        return setup_frame_workload(model, per_gpu, wl['T'], args, world, rank, load_tune if tune else None,
+                                    save_tune if tune else None)
 
     full_model = None
     if args.workload == 'speed2d':
@@ -849,6 +912,13 @@ def main():
                     'collective_us': round(1e3 * float(np.mean([a.elapsed_time(b) for a, b in cpairs])), 2),
                     'outputs_finite_in_range': bool(np.all(np.isfinite(cpose)) and cpose.min() >= 0 and cpose.max() <= 1)}
 
+    # [r06] ... and, at N = 1, compact legs of the other BASELINE configurations and of the reference's speed protocol
+    extra_legs = {}
+    if args.workload == 'mpii' and world == 1 and not args.no_extra_legs and not args.no_clip_leg and args.input == 'f32' \
+            and model.gemm_precision == 'f32':
+        for w in ('h36m', 'ntu_spnet', 'speed2d'):
+            extra_legs[w] = compact_leg(w, args, rank)
+
     if rank == 0:
         out = {
             'metric': 'frames/sec whole-node, 256x256 MPII pose fwd' if args.workload == 'mpii' else
@@ -885,6 +955,7 @@ def main():
             out['frame_sharded_clips'] = clip_leg
         if split_leg is not None:
             out['bf16x3'] = split_leg
+        out.update(extra_legs)
         if args.workload == 'mpii' and world == 1 and not args.no_predict:
             fps = predict_boundary(model, per_gpu, args.predict_frames)
             out['predict_fps_f32'], out['predict_fps_u8'] = fps['f32'], fps['u8']

@@ -100,6 +100,7 @@ SIGNATURES = {
     'dh_stream_destroy': (C.c_int, [vp]),
     'dh_event_create_sync': (C.c_int, [C.POINTER(vp)]),
     'dh_stream_wait_event': (C.c_int, [vp, vp]),
+    'dh_stream_spin_us': (C.c_int, [vp, C.c_int]),
 }
 
 _lib = None

@@ -263,4 +263,15 @@ int dh_stream_wait_event(void* stream, void* event) {
   return rc_of(hipStreamWaitEvent(S(stream), reinterpret_cast<hipEvent_t>(event), 0));
 }
 
+// one wave that holds its stream for `us` microseconds (constant-rate 100 MHz counter; bounded by an iteration cap)
+__global__ void spin_kernel(long long ticks) {
+  const long long t0 = wall_clock64();
+  for (int i = 0; i < (1 << 22) && wall_clock64() - t0 < ticks; ++i) __builtin_amdgcn_s_sleep(8);
+}
+int dh_stream_spin_us(void* stream, int us) {
+  if (us < 0 || us > 20000) return DH_EINVAL;
+  hipLaunchKernelGGL(spin_kernel, dim3(1), dim3(64), 0, S(stream), (long long)us * 100);
+  return check_launch();
+}
+
 }  // extern "C"

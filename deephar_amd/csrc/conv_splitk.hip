@@ -192,7 +192,7 @@ __global__ __launch_bounds__(NWV * 64) void conv_skinny_kernel(const ConvArgs p,
 template <int NWV>
 int launch_skinny(const ConvArgs& a, unsigned tiles, bool vec, hipStream_t s) {
   const unsigned magic_cin = (unsigned)((1ull << 32) / (unsigned)a.Cin + 1ull);       // k / Cin = umulhi(k, magic), k * Cin < 2^32
-  const unsigned magic_kw = (1u << 16) / (unsigned)a.KW + 1u;                          // tap / KW for tap < 2^8
+  const unsigned magic_kw = (1u << 16) / (unsigned)a.KW + 1u;                          // tap / KW for tap, KW < 2^8 (conv_is_skinny)
   const size_t lds = ((size_t)NWV * 4 * 64 + (a.pre_scale != nullptr ? (size_t)2 * ((a.Cin + 3) & ~3) : 0)) * sizeof(float);
   constexpr int lds_max = (NWV * 4 * 64 + 2 * SK_MAX_CIN) * (int)sizeof(float);      // <= 48 KB
   if (vec) {
@@ -215,8 +215,10 @@ int launch_skinny(const ConvArgs& a, unsigned tiles, bool vec, hipStream_t s) {
 // Cin % 4 == 0 -- the action heads' 1x1 / 3x3 convolutions with K = 70 .. 720 ran 15-33 us on one wave per tile.]
 bool conv_is_skinny(const ConvArgs& a) {
   if (a.x_u8 || a.w_split) return false;
-  return a.OH * a.OW <= 256 && a.K >= 64 && a.Cout <= 256 && a.Cin >= 2 && a.Cin <= SK_MAX_CIN && a.KW < 256 &&
-         (long long)a.K * a.Cin < (1ll << 31);
+  // kernel extent: `locate` decodes tap -> (kh, kw) as (tap * magic_kw) >> 16, exact while tap * KW < 2^16 -- KH * KW < 256
+  // keeps tap < 256 and KW < 256 (KW < 256 alone admitted KW = 255, KH >= 2, where tap >= 258 decodes wrong)
+  return a.OH * a.OW <= 256 && a.K >= 64 && a.Cout <= 256 && a.Cin >= 2 && a.Cin <= SK_MAX_CIN && a.KH >= 1 && a.KW >= 1 &&
+         (long long)a.KH * a.KW < 256 && (long long)a.K * a.Cin < (1ll << 31);
 }
 
 // waves per tile: from K alone (16 k per quad, eight quads per wave and chunk)

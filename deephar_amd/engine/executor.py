@@ -160,6 +160,9 @@ class BoundPlan:
         self.calls = []       # (fn, args tuple without stream, step)
         self._keep = []       # ctypes structs kept alive
         self.graph = None
+        # test hook (schedule stress tests): called as perturb(call index, step, stream of the step, [all streams]) right
+        # before every launch of launch_all -- e.g. to put dh_stream_spin_us delays on one stream
+        self.perturb = None
         # uint8 frames: every model input gets a byte staging buffer; convolutions that read an input directly
         # normalise on load (dh_conv_args.x_u8), anything else is fed by a stand-alone normalisation launch
         self.u8 = None
@@ -412,7 +415,9 @@ class BoundPlan:
         back into `stream_ptr` (so the sequence is capturable into one hipGraph)."""
         lib = self.lib
         if self.plan.nstreams <= 1:
-            for fn, args, step in self.calls:
+            for i, (fn, args, step) in enumerate(self.calls):
+                if self.perturb is not None:
+                    self.perturb(i, step, stream_ptr, [stream_ptr])
                 rc = fn(*args, stream_ptr)
                 if rc != 0:
                     _lib.check(rc, 'step %s (%s)' % (step.kind, step.name))
@@ -445,6 +450,8 @@ class BoundPlan:
                     _lib.check(lib.dh_event_record(self._relay[key], stream_ptr), 'relay record')
                     ev = self._relay[key]
                 _lib.check(lib.dh_stream_wait_event(sp, ev), 'dependency wait')
+            if self.perturb is not None:
+                self.perturb(i, step, sp, ptrs)
             rc = fn(*args, sp)
             if rc != 0:
                 _lib.check(rc, 'step %s (%s)' % (step.kind, step.name))

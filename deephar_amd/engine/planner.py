@@ -68,10 +68,12 @@ class Value:
         return int(np.prod(self.shape[:-nd])) if len(self.shape) > nd else 1
 
 
-def split_k_rule(out_pixels, K, cout, cin):
-    """Mirror of conv_is_skinny (csrc/conv_splitk.hip; dh_conv2d_uses_split_k): the layers dh_conv2d_f32 runs on its
-    in-work-group split-K kernel -- per-frame geometry only, so a layer's bits depend on neither batch size nor tiling."""
-    return out_pixels <= 256 and K >= 64 and cout <= 256 and 2 <= cin <= 4096
+def split_k_rule(out_pixels, K, cout, cin, kh=1, kw=1):
+    """Mirror of conv_is_skinny (csrc/conv_splitk.hip; dh_conv2d_uses_split_k) for float inputs and fp32-packed weights:
+    the layers dh_conv2d_f32 runs on its in-work-group split-K kernel -- per-frame geometry only, so a layer's bits depend
+    on neither batch size nor tiling.  Every clause of the C++ rule is stated here (the two had drifted apart
+    on the kernel-extent clauses); tests/test_host_logic.py sweeps both over the same shapes."""
+    return out_pixels <= 256 and K >= 64 and cout <= 256 and 2 <= cin <= 4096 and kh * kw < 256 and K * cin < (1 << 31)
 
 
 class ConcatParam:
@@ -294,8 +296,11 @@ class Planner:
         return self.val[t.uid]
 
     # consumers that read a tensor through a (pointer, pixel pitch) view whatever its pitch: they may share a producer's
-    # output with ONE concatenate, which then needs no copy (R4b)
-    _VIEW_READERS = ('softmax2d', 'jointprob', 'globalmax2d', 'conv')
+    # output with ONE concatenate, which then needs no copy (R4b).  Convolutions are NOT in the list: no
+    # shipped model needs it, and a 1x1 convolution on the LDS-DMA GEMM whose Cin is not a multiple of its K-step fills
+    # the padded k slots of a pixel from the floats that follow it in memory -- inside a shared slab that is the
+    # neighbouring tensor, possibly not written yet (0 * NaN from an uninitialised arena)
+    _VIEW_READERS = ('softmax2d', 'jointprob', 'globalmax2d')
 
     def _concat_home(self, t):
         """The concatenate whose buffer t's producer writes into (R4): t's only consumer -- or [r05, R4b] the only
@@ -385,7 +390,7 @@ class Planner:
             if ya.buf is not yb.buf or ya.ld != yb.ld or ya.shape[:-1] != yb.shape[:-1] or ya.coff + ya.C != yb.coff:
                 return False
             px = ya.shape[-3] * ya.shape[-2] if len(ya.shape) >= 3 else 1
-            fam = lambda c: split_k_rule(px, a.attrs['K'], c, a.attrs['Cin'])
+            fam = lambda c: split_k_rule(px, a.attrs['K'], c, a.attrs['Cin'], a.attrs['kh'], a.attrs['kw'])
             return fam(ya.C) == fam(yb.C) == fam(ya.C + yb.C)
 
         steps = self.plan.steps
@@ -512,7 +517,8 @@ class Planner:
             return False
         cin = node.inputs[0].shape[-1]
         K = cin if node.op == 'sepconv' else a['kh'] * a['kw'] * cin
-        return split_k_rule(shape[-3] * shape[-2], K, a['filters'], cin)
+        kh, kw = (1, 1) if node.op == 'sepconv' else (a['kh'], a['kw'])
+        return split_k_rule(shape[-3] * shape[-2], K, a['filters'], cin, kh, kw)
 
     def _epilogue(self, out_t, skinny=False):
         """Walk conv -> bn -> relu -> add -> (upsample -> add) while each link has a single consumer.  `skinny`: the
@@ -576,7 +582,7 @@ class Planner:
 
     def _emit_conv(self, x, pre_bn, pre_relu, param, a, out_t, name):
         skinny = len(out_t.shape) >= 3 and split_k_rule(out_t.shape[-3] * out_t.shape[-2], a['kh'] * a['kw'] * x.C,
-                                                        a['filters'], x.C)
+                                                        a['filters'], x.C, a['kh'], a['kw'])
         epi, final_t = self._epilogue(out_t, skinny)
         y = self.out_value_for(final_t)
         attrs = dict(kh=a['kh'], kw=a['kw'], sh=a.get('sh', 1), sw=a.get('sw', 1), pt=a['pt'], pl=a['pl'],
@@ -705,7 +711,8 @@ class Planner:
                 x.shape[-2] == 32 and x.shape[-3] % 2 == 0 and x.C % 4 == 0 and x.ld % 4 == 0 and y.ld % 4 == 0 and \
                 x.coff % 4 == 0 and y.coff % 4 == 0 and \
                 not (prod.attrs['kh'] * prod.attrs['kw'] > 1 and prod.attrs['Cin'] % 32 == 16) and \
-                not split_k_rule(x.shape[-3] * x.shape[-2], prod.attrs['K'], prod.attrs['Cout'], prod.attrs['Cin']):
+                not split_k_rule(x.shape[-3] * x.shape[-2], prod.attrs['K'], prod.attrs['Cout'], prod.attrs['Cin'],
+                                 prod.attrs['kh'], prod.attrs['kw']):
             prod.outs['ypool'] = y
             prod.attrs['pool2'] = 1
             self.producer[id(y)] = prod

@@ -119,6 +119,10 @@ def assign_streams_tail(plan, deps, items=2, nstreams=2):
     heads' front ends, which then run ahead of the chain.
     s and x minimise the simulated makespan under a per-step cost of a launch floor plus the step's arithmetic / bytes
     for `items` batch items; no split is made when it would not save 5 % of the serial time.
+    `items` = 2 and the cost constants (7.5 us per launch, 90 TFLOP/s, 3 TB/s) are those of the regime the policy exists
+    for -- two clips per call on an MI355X.  A Plan serves every batch size it is later bound to, so the split
+    is NOT re-tuned per batch: any split is correct and bit-identical (the waits follow the data dependencies), a batch far
+    from two clips merely runs a split balanced for two.  Throughput-regime callers keep the default (one stream).
     -> (stream per step, new order of the steps) -- the order stays topological."""
     import heapq
     n = len(plan.steps)

@@ -22,6 +22,9 @@ class CallRec:
         self.model, self.inputs, self.outputs = model, list(inputs), list(outputs)
 
 
+_ENGINE_CHOICES = {'stream_policy': ('list', 'tail'), 'gemm_precision': ('f32', 'bf16x3')}
+
+
 class Model:
     def __init__(self, inputs, outputs, name=None):
         self._single_in = not isinstance(inputs, (list, tuple))
@@ -68,6 +71,8 @@ class Model:
             return self.__dict__['_opt_' + name]
 
         def set_(self, value):
+            if name in _ENGINE_CHOICES and value not in _ENGINE_CHOICES[name]:      # (a typo fails here, not at the first predict)
+                raise ValueError('%s must be one of %s, got %r' % (name, '/'.join(map(repr, _ENGINE_CHOICES[name])), value))
             if self.__dict__.get('_opt_' + name, value) != value and self.__dict__.get('_plan') is not None:
                 self._plan, self._exec = None, None
             self.__dict__['_opt_' + name] = value

@@ -311,6 +311,10 @@ int dh_stream_create(void** stream_out);
 int dh_stream_destroy(void* stream);
 int dh_event_create_sync(void** event_out); /* hipEventDisableTiming */
 int dh_stream_wait_event(void* stream, void* event);
+/* test aid for multi-stream schedules: one idle wave occupies `stream` for about `us` microseconds (<= 20 000), so a
+ * test can delay one stream of a plan against the others and check that every cross-stream dependency is an event wait
+ * (tests/test_gpu_speed2d.py: the 'tail' policy of the latency regime under random delays). */
+int dh_stream_spin_us(void* stream, int us);
 
 #ifdef __cplusplus
 }

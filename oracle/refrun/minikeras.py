@@ -209,7 +209,17 @@ class SeparableConv2D(Layer):
         if self.padding == 'same':
             xc = _pad_nchw(xc, x.shape[1], x.shape[2], self.k, self.s)
         dw = self.weights[0].permute(2, 3, 0, 1).contiguous()
-        y = F.conv2d(xc, dw, stride=self.s, groups=c)
+        if self.padding != 'same' and tuple(xc.shape[-2:]) == tuple(self.k):
+            # a kernel as large as the map (the reference's soft-argmax, layers.py:160-200: one output position = the sum
+            # of H*W products per channel): summed with torch.sum's cascade summation.  [r06] torch's CPU depthwise-conv
+            # kernel accumulates the 1 024 taps of a 32 x 32 map one after the other in fp32 and lands ~100 ulp =
+            # 1.2-1.8e-3 px from the fp64 result on broad heat-maps (measured on the exact fp64 logits of the real-size
+            # SPNet goldens; (p * w).sum() on the same data: 8e-5 px) -- an artefact of THAT kernel's order, which would
+            # have made this stand-in's fp32 run a worse fp32 reference than any real backend.  Same products, same
+            # result in exact arithmetic; the fp64 goldens move by ~1e-16.
+            y = (xc * dw[:, 0]).sum(dim=(-2, -1), keepdim=True)
+        else:
+            y = F.conv2d(xc, dw, stride=self.s, groups=c)
         pw = self.weights[1].permute(3, 2, 0, 1).contiguous()
         return F.conv2d(y, pw).permute(0, 2, 3, 1)
 

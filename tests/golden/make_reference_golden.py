@@ -14,7 +14,10 @@ either as a shape mismatch here or as a numeric mismatch in tests/test_reference
          oracle; the fitted head kernels are stored beside the outputs, '<tag>/head/<layer name>')
     python tests/golden/make_reference_golden.py --real     ->  tests/golden/reference_models_real.npz
         (the BASELINE configurations at their REAL size: ReceptionNet 8 blocks 2-D / 3-D at 256 px, the merge model of
-         eval_penn_ar_pe_merge.py at T = 16 / 4 blocks / 256 px, SPNet-NTU at T = 32 / 256 px with fitted heads)
+         eval_penn_ar_pe_merge.py at T = 16 / 4 blocks / 256 px, SPNet-NTU at T = 32 / 256 px with fitted heads, and
+         [r06] the model of the reference's own speed protocol, eval_speed2d.py:31-43: SPNet-Penn, 6 pyramids, actions
+         on all six, pose_replica, T = 8 at 256 px, fitted heads)
+    ... --real --only=spnet2d_speed_s,spnet3d_32_s           (recompute just these cases of the file)
 """
 import importlib
 import os
@@ -118,7 +121,7 @@ def draw(tag, shape):
 TAGS = ('rec2d', 'rec3d', 'merge2d', 'merge3d', 'spnet3d', 'spnet2d', 'spnet2dr')
 SMOOTH_TAGS = ('spnet3d_s', 'spnet2d_s', 'spnet2dr_s')
 OUT_SMOOTH = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'reference_models_smooth.npz')
-REAL_TAGS = ('rec2d_8', 'rec3d_8', 'merge2d_16', 'spnet3d_32_s')
+REAL_TAGS = ('rec2d_8', 'rec3d_8', 'merge2d_16', 'spnet3d_32_s', 'spnet2d_speed_s')
 OUT_REAL = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'reference_models_real.npz')
 
 
@@ -181,7 +184,9 @@ def build_pair(R, tag):
                                                 'spnet2d': (16, 'pa16j2d', 15, 2, [2], 160, 128, False),
                                                 'spnet2dr': (8, 'pa16j2d', 15, 6, [5, 6], 160, 128, True),
                                                 # configs[4]: T = 32 -> time_stride 2 (spnet.py:100), 256 px
-                                                'spnet3d_32': (32, 'pa17j3d', 60, 2, [1, 2], 192, 256, False)}[
+                                                'spnet3d_32': (32, 'pa17j3d', 60, 2, [1, 2], 192, 256, False),
+                                                # exp/pennaction/eval_speed2d.py:31-43: the model the reference times
+                                                'spnet2d_speed': (8, 'pa16j2d', 15, 6, [1, 2, 3, 4, 5, 6], 160, 256, True)}[
         tag[:-2] if smooth else tag]
     R['models.spnet'].__dict__.pop('act_cnt', None)       # the reference's process-global counter
     rcfg = R['config'].ModelConfig((T, res, res, 3), getattr(putils, lay), num_actions=[nact], num_pyramids=pyr,
@@ -249,14 +254,24 @@ def check_weight_files(tag, ref_model, product_model):
           ('by name' if by_name else 'by order', 'n/a (by-name family)' if by_name else 'by order'))
 
 
-def main(smooth=False, real=False):
+def main(smooth=False, real=False, only=None):
+    """only: comma list of tags -- just these cases are recomputed, the other arrays of the output file are kept as they
+    are (a full run reproduces them bit for bit; this keeps an added or refitted case to minutes)."""
     import json
     import time
     from deephar_amd import weights
     R = load_reference()
     g = {}
     layouts = {}
-    for tag in (REAL_TAGS if real else SMOOTH_TAGS if smooth else TAGS):
+    tags = REAL_TAGS if real else SMOOTH_TAGS if smooth else TAGS
+    out = OUT_REAL if real else OUT_SMOOTH if smooth else OUT
+    if only:
+        assert smooth or real, '--only is for the outputs-only files (--smooth / --real)'
+        assert all(t in tags for t in only), (only, tags)
+        old = np.load(out)
+        g = {k: old[k] for k in old.files if k.split('/')[0] not in only}
+        tags = [t for t in tags if t in only]
+    for tag in tags:
         t0 = time.time()
         ref_model, product_model, x = build_pair(R, tag)
         weights.init_synthetic(product_model, seed=0)
@@ -264,7 +279,8 @@ def main(smooth=False, real=False):
             import refgolden
             import wellcond
             heads = wellcond.fit_spnet_heads(product_model, refgolden.spnet_ocfg(tag), x.astype(np.float32),
-                                             refgolden.smooth_input(tag)[1])
+                                             refgolden.smooth_input(tag)[1],
+                                             per_joint=tag[:-2] in refgolden.FIT_PER_JOINT)
             for name, k in heads.items():
                 g['%s/head/%s' % (tag, name)] = k
         n = transfer_weights(product_model, ref_model)
@@ -277,7 +293,6 @@ def main(smooth=False, real=False):
                 g['%s/%s/%d' % (tag, k, i)] = a.astype(np.float64 if k == 'f64' else np.float32)
         g['%s/nout' % tag] = np.array(len(outs['f64']))
         print(tag, 'outputs', [a.shape for a in outs['f64']], 'weights set', n, '%.0f s' % (time.time() - t0), flush=True)
-    out = OUT_REAL if real else OUT_SMOOTH if smooth else OUT
     if not smooth and not real:
         with open(os.path.join(os.path.dirname(OUT), 'keras_layouts.json'), 'w') as fh:
             json.dump(layouts, fh, separators=(',', ':'))
@@ -286,4 +301,5 @@ def main(smooth=False, real=False):
 
 
 if __name__ == '__main__':
-    main(smooth='--smooth' in sys.argv, real='--real' in sys.argv)
+    only = next((a.split('=', 1)[1].split(',') for a in sys.argv if a.startswith('--only=')), None)
+    main(smooth='--smooth' in sys.argv, real='--real' in sys.argv, only=only)

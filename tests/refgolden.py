@@ -18,9 +18,19 @@ GOLDEN_REAL = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden',
 SPNET_CASES = {'spnet3d': (4, 'pa17j3d', 60, 2, [1, 2], 192, False),
                'spnet2d': (16, 'pa16j2d', 15, 2, [2], 160, False),
                'spnet2dr': (8, 'pa16j2d', 15, 6, [5, 6], 160, True),
-               'spnet3d_32': (32, 'pa17j3d', 60, 2, [1, 2], 192, False)}
-SPNET_RES = {'spnet3d_32': 256}          # input resolution (default 128)
-SMOOTH_SEED = 31
+               'spnet3d_32': (32, 'pa17j3d', 60, 2, [1, 2], 192, False),
+               # [r06] the model of the reference's speed protocol, exp/pennaction/eval_speed2d.py:31-43: six pyramids,
+               # actions on ALL six, pose_replica=True, 8-frame clips at 256 px (18 pose + 18 action outputs)
+               'spnet2d_speed': (8, 'pa16j2d', 15, 6, [1, 2, 3, 4, 5, 6], 160, True)}
+SPNET_RES = {'spnet3d_32': 256, 'spnet2d_speed': 256}          # input resolution (default 128)
+# seed of the video clip / peak positions of a '<tag>_s' case (31 + the case's rank among the round-5 cases; fixed numbers
+# since round 6 so that a new case does not move the old ones)
+SMOOTH_SEEDS = {'spnet2d': 31, 'spnet2dr': 32, 'spnet3d': 33, 'spnet3d_32': 34, 'spnet2d_speed': 35}
+# cases whose heads are fitted with one bisection factor PER JOINT (wellcond._scale_per_joint, the round-4 rule of
+# tests/test_gpu_spnet_flat.py); the others keep the common factor their committed goldens were made with.  [r06]
+# 'spnet3d_32' moved here: under the common factor the reference code's own fp32 run sat 1.0e-3 px from its fp64 run
+# (a vector that cannot resolve the bar in plain fp32)
+FIT_PER_JOINT = ('spnet3d_32', 'spnet2d_speed')
 
 
 def case_input(tag, shape):
@@ -35,7 +45,7 @@ def smooth_input(tag, res=None):
     T, lay = SPNET_CASES[tag[:-2]][:2]
     res = res or SPNET_RES.get(tag[:-2], 128)
     J = getattr(utils, lay).num_joints
-    seed = SMOOTH_SEED + sorted(SPNET_CASES).index(tag[:-2])
+    seed = SMOOTH_SEEDS[tag[:-2]]
     return wellcond.video_clips(1, T, res, seed), wellcond.joint_positions(1, T, J, seed)
 
 
@@ -129,4 +139,4 @@ def build_case(tag):
 
 CASES = ['rec2d', 'rec3d', 'merge2d', 'merge3d', 'spnet3d', 'spnet2d', 'spnet2dr']
 SMOOTH_CASES = ['spnet3d_s', 'spnet2d_s', 'spnet2dr_s']
-REAL_CASES = ['rec2d_8', 'rec3d_8', 'merge2d_16', 'spnet3d_32_s']
+REAL_CASES = ['rec2d_8', 'rec3d_8', 'merge2d_16', 'spnet3d_32_s', 'spnet2d_speed_s']

@@ -471,12 +471,19 @@ def test_split_k_rule_matches_the_library(hip_lib):
                 for cout in (15, 48, 256, 257, 576):
                     a.N, a.OH, a.OW, a.Cin, a.Cout, a.KH, a.KW, a.K = 3, oh, ow, cin, cout, k, k, k * k * cin
                     a.x_u8 = a.w_split = 0
-                    assert bool(hip_lib.dh_conv2d_uses_split_k(C.byref(a))) == split_k_rule(oh * ow, k * k * cin, cout, cin), \
+                    assert bool(hip_lib.dh_conv2d_uses_split_k(C.byref(a))) == split_k_rule(oh * ow, k * k * cin, cout, cin, k, k), \
                         (oh, ow, k, cin, cout)
                     n += 1
+    # the kernel-extent clauses: KH * KW < 256 (the tap decode), K * Cin < 2^31
+    for kh, kw, cin in ((1, 255, 4), (2, 255, 4), (16, 16, 4), (15, 17, 4), (1, 3, 4096), (5, 5, 4096), (11, 11, 4096), (3, 3, 4097)):
+        a.N, a.OH, a.OW, a.Cin, a.Cout, a.KH, a.KW, a.K = 1, 4, 4, cin, 64, kh, kw, kh * kw * cin
+        assert bool(hip_lib.dh_conv2d_uses_split_k(C.byref(a))) == split_k_rule(16, kh * kw * cin, 64, cin, kh, kw), (kh, kw, cin)
+        n += 1
+    assert not split_k_rule(16, 2 * 255 * 4, 64, 4, 2, 255) and split_k_rule(16, 255 * 4, 64, 4, 1, 255)
     a.w_split = 1
     assert hip_lib.dh_conv2d_uses_split_k(C.byref(a)) == 0            # split-packed weights never take that kernel
     assert n > 500
+
 
 
 def test_engine_options_replan_the_model():

@@ -41,11 +41,17 @@ def test_oracle_matches_reference_code_at_real_size(tag):
         assert np.abs(a - b).max() <= 1e-9 * max(1.0, np.abs(b).max()), (tag, k, np.abs(a - b).max())
 
 
-@pytest.mark.parametrize('tag', SMOOTH_CASES)
+# [r06] the two real-size SPNet goldens must be resolvable in plain fp32 with a factor of two to spare: the round-5 fit of
+# 'spnet3d_32_s' left the reference code's own fp32 run 1.0e-3 px from its fp64 run
+TIGHT = {'spnet3d_32_s': 5e-4, 'spnet2d_speed_s': 5e-4}
+
+
+@pytest.mark.parametrize('tag', SMOOTH_CASES + sorted(TIGHT))
 def test_smooth_goldens_are_well_conditioned(tag):
     """The '<tag>_s' goldens (reference code on tests/wellcond.py vectors) are what the flat 1e-3 px SPNet tests stand
     on: every prediction block's read-out sensitivity S <= 0.05, maps not one-hot, and plain fp32 arithmetic (the
-    reference code's own fp32 run) within 1e-3 px of its fp64 run -- i.e. these vectors can resolve the bar."""
+    reference code's own fp32 run) within 1e-3 px of its fp64 run (5e-4 px for the real-size cases) -- i.e. these vectors
+    can resolve the bar."""
     import wellcond
     _, _, run = build_case(tag)
     t64 = {}
@@ -56,7 +62,7 @@ def test_smooth_goldens_are_well_conditioned(tag):
     for a, b in zip(g32, g64):
         if b.ndim == 4:          # poses [1, T, J, dim + 1]
             d = b.shape[-1] - 1
-            assert 256.0 * np.abs(a[..., :d] - b[..., :d]).max() <= 1e-3, tag
+            assert 256.0 * np.abs(a[..., :d] - b[..., :d]).max() <= TIGHT.get(tag, 1e-3), tag
 
 
 @pytest.mark.skipif(not os.path.isdir('/root/reference/deephar'), reason='needs the reference checkout')
