@@ -23,7 +23,7 @@ class ConvArgs(C.Structure):
 
 class DwArgs(C.Structure):
     _fields_ = [(n, vp) for n in ('x', 'w', 'y', 'pre_scale', 'pre_shift')] + \
-               [(n, i32) for n in ('N', 'H', 'W', 'C', 'ldx', 'ldy', 'KH', 'KW', 'PT', 'PL', 'pre_relu')]
+               [(n, i32) for n in ('N', 'H', 'W', 'C', 'ldx', 'ldy', 'KH', 'KW', 'PT', 'PL', 'pre_relu', 'up_in')]
 
 
 class PoolArgs(C.Structure):

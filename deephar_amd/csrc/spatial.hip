@@ -51,14 +51,16 @@ __global__ __launch_bounds__(256) void dwconv_kernel(const DwArgs p) {
     for (int kh = 0; kh < KS; ++kh) {   // one row of taps at a time keeps ~110 VGPRs (4 waves/SIMD)
       const int ih = oh - p.PT + kh;
       const bool rok = (unsigned)ih < (unsigned)p.H;
-      const float* row = p.x + ((size_t)(n * p.H + (rok ? ih : 0)) * p.W) * p.ldx + c;
+      // up_in: x is stored at half resolution and read as UpSampling2D((2, 2))(x): input pixel (ih, iw) = x(ih / 2, iw / 2)
+      const int ush = p.up_in ? 1 : 0;
+      const float* row = p.x + ((size_t)(n * (p.H >> ush) + ((rok ? ih : 0) >> ush)) * (p.W >> ush)) * p.ldx + c;
       // all loads of the row are issued unconditionally (clamped), masked afterwards: no wait between them
       float4 in[TW + KS - 1];
 #pragma unroll
       for (int j = 0; j < TW + KS - 1; ++j) {
         const int iw = ow0 - p.PL + j;
         const bool ok = (unsigned)iw < (unsigned)p.W;
-        in[j] = ld4(row + (size_t)(ok ? iw : 0) * p.ldx);
+        in[j] = ld4(row + (size_t)((ok ? iw : 0) >> ush) * p.ldx);
       }
       float4 wv[KS];
 #pragma unroll
@@ -157,9 +159,14 @@ __global__ __launch_bounds__(NT) void dwconv_lds_kernel(const DwArgs p, const in
   float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = zero;
   if constexpr (AFF) { sc = ld4(p.pre_scale + c0 + q * 4); sh = ld4(p.pre_shift + c0 + q * 4); }
 
+  // up_in: x is stored at HALF resolution, [N, H / 2, W / 2, C], and read as UpSampling2D((2, 2))(x) -- window pixel (r, c)
+  // is x(r >> 1, c >> 1); rows / columns outside the full-resolution frame stay out-of-range offsets (an arithmetic shift
+  // keeps a negative row negative, a row >= H lands behind the half-resolution frame)
+  const int ush = p.up_in ? 1 : 0;
+  const int hw_in = (p.H >> ush) * (p.W >> ush), w_in = p.W >> ush;
   const auto rs_x = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<float*>(p.x) + (size_t)n * p.H * p.W * p.ldx, 0,
-      (int)(((unsigned)(p.H * p.W - 1) * p.ldx + (unsigned)p.C) * 4u), 0x00020000);
+      const_cast<float*>(p.x) + (size_t)n * hw_in * p.ldx, 0,
+      (int)(((unsigned)(hw_in - 1) * p.ldx + (unsigned)p.C) * 4u), 0x00020000);
   const auto rs_y = __builtin_amdgcn_make_buffer_rsrc(
       p.y + (size_t)n * p.H * p.W * p.ldy, 0, (int)(((unsigned)(p.H * p.W - 1) * p.ldy + (unsigned)p.C) * 4u), 0x00020000);
   const int row_bytes = twh * DW_PITCH * 16, ring_bytes = th * row_bytes;
@@ -169,7 +176,7 @@ __global__ __launch_bounds__(NT) void dwconv_lds_kernel(const DwArgs p, const in
   auto px_offset = [&](int px, int first_row) {     // frame byte offset of window pixel px, window starting at first_row
     const int tr = row_of(px), tc = px - tr * twh;
     const int iw = w0 - p.PL + tc;
-    return (unsigned)iw < (unsigned)p.W ? (((first_row + tr) * p.W + iw) * p.ldx + c0 + q * 4) * 4 : DW_OOB;
+    return (unsigned)iw < (unsigned)p.W ? ((((first_row + tr) >> ush) * w_in + (iw >> ush)) * p.ldx + c0 + q * 4) * 4 : DW_OOB;
   };
 
   // ---- the KS - 1 rows above the first band (input rows -PT .. KS - 2 - PT) go to ring rows 0 .. KS - 2, once
@@ -214,7 +221,7 @@ __global__ __launch_bounds__(NT) void dwconv_lds_kernel(const DwArgs p, const in
   // CU covers the wait.
   float4 stage[MAXN];
   auto fetch = [&](int band) {
-    const int boff = band * rows * p.W * p.ldx * 4;
+    const int boff = band * (rows >> ush) * w_in * p.ldx * 4;          // (up_in: bands of an even number of rows, see launch)
 #pragma unroll
     for (int j = 0; j < MAXN; ++j) stage[j] = buf_ld4(rs_x, voff[j] + boff);
   };
@@ -295,7 +302,8 @@ __global__ __launch_bounds__(256) void dwconv_generic_kernel(const DwArgs p) {
       for (int kw = 0; kw < p.KW; ++kw) {
         const int iw = ow - p.PL + kw;
         if ((unsigned)iw >= (unsigned)p.W) continue;
-        float v = p.x[((size_t)(n * p.H + ih) * p.W + iw) * p.ldx + c];
+        const int ush = p.up_in ? 1 : 0;
+        float v = p.x[((size_t)(n * (p.H >> ush) + (ih >> ush)) * (p.W >> ush) + (iw >> ush)) * p.ldx + c];
         if (p.pre_scale != nullptr) v = fmaf(v, p.pre_scale[c], p.pre_shift[c]);
         if (p.pre_relu) v = fmaxf(v, 0.f);
         acc = fmaf(v, p.w[(size_t)(kh * p.KW + kw) * p.C + c], acc);
@@ -477,6 +485,7 @@ int launch_dw_lds(const DwArgs& a, int tw, int rows, int nt, unsigned blocks, si
 
 int launch_dwconv(const DwArgs& a, hipStream_t s) {
   if (a.N <= 0 || a.C <= 0 || a.KH <= 0 || a.KW <= 0) return DH_EINVAL;
+  if (a.up_in && ((a.H & 1) || (a.W & 1))) return DH_EINVAL;        // an up-sampled input has even extents
   const bool vec = (a.C % 4 == 0) && (a.ldx % 4 == 0) && (a.ldy % 4 == 0) && al16(a.x) && al16(a.y) &&
                    al16(a.w) && (a.pre_scale == nullptr || (al16(a.pre_scale) && al16(a.pre_shift)));
   if (vec && a.KH == a.KW && (a.KW == 5 || a.KW == 3) && a.C % 32 == 0 && a.W >= DW_LDS_MIN_W && a.W % 8 == 0) {
@@ -488,7 +497,7 @@ int launch_dwconv(const DwArgs& a, hipStream_t s) {
     const int tw = a.W >= 32 ? 32 : a.W;
     const int nt = tw == 8 ? 64 : 256;
     int rows = nt / (8 * (tw / 8));
-    if (rows > a.H) rows = a.H;
+    if (rows > a.H) rows = a.H;                                      // (8 or 16, or the even H of an up-sampled input: even)
     const long long blocks = (long long)a.N * ((a.W + tw - 1) / tw) * (a.C / 32);    // bands are walked inside
     const size_t lds = ((size_t)(rows + a.KW - 1) * (tw + a.KW - 1) * DW_PITCH + (size_t)a.KW * a.KW * DW_CQ + 1) * 16;
     const bool fits31 = (long long)a.H * a.W * a.ldx * 4 < 0x7fffffffLL && (long long)a.H * a.W * a.ldy * 4 < 0x7fffffffLL;

@@ -268,9 +268,10 @@ class BoundPlan:
             if 'pre_bn' in s.params:
                 sc, sh = self.store.bn_affine(s.params['pre_bn'])
                 args.pre_scale, args.pre_shift = sc.data_ptr(), sh.data_ptr()
-            args.N, args.H, args.W, args.C = n * x.lead(3), x.shape[-3], x.shape[-2], x.C
+            args.N, args.H, args.W, args.C = n * y.lead(3), y.shape[-3], y.shape[-2], x.C      # (up_in: x is at half resolution)
             args.ldx, args.ldy = x.ld, y.ld
             args.KH, args.KW, args.PT, args.PL, args.pre_relu = a['kh'], a['kw'], a['pt'], a['pl'], a['pre_relu']
+            args.up_in = a.get('up_in', 0)
             self._keep.append(args)
             self.calls.append((lib.dh_dwconv2d_f32, (C.byref(args),), s))
         elif k == 'pool':

@@ -23,6 +23,13 @@ Fusion rules (what the reference leaves to TensorFlow as separate kernels):
                 residual slot (spnet.py:303) -- no element-wise launches are left for either.
   R5 decoder  : channel soft-max + both lin_interpolation_2d + joint confidence (+ global max) on the same
                 maps are one soft-argmax kernel (blocks.py:306-343).
+  R11 up-unit : [r06] UpSampling2D in FRONT of a residual unit (SPNet's up-scaling unit, common.py:89-108:
+                residual_unit(UpSampling2D(x)) -- BN, then a 1x1 shortcut convolution and a separable convolution, both of
+                relu(BN(.))) is never written out: nearest up-sampling commutes with everything element-wise and with a
+                1x1 convolution, so the shortcut runs at HALF resolution (a quarter of the work; its result is the
+                half-resolution second residual of the separable convolution's pointwise half, dh_conv_args.res2_down) and
+                the depthwise half reads the half-resolution tensor as if up-sampled (dh_dw_args.up_in).  Same products, same
+                sums; only the order of the two residual additions changes.
 All tensors are fp32; sizes are tracked per batch item so one plan serves any batch size.
 """
 import os
@@ -160,6 +167,14 @@ class _Lazy:
         self.relu = relu
 
 
+class _UpView:
+    """A nearest-up-sampled tensor that has not been written out (R11): `low` = the Value at half resolution, `shape` = the
+    logical (up-sampled) shape, `full` = the materialised Value once some consumer needed one."""
+
+    def __init__(self, low, shape):
+        self.low, self.shape, self.full = low, tuple(shape), None
+
+
 class Planner:
     def __init__(self, inputs, outputs, nstreams=1, stream_policy='list'):
         self.nstreams = nstreams
@@ -284,6 +299,10 @@ class Planner:
     def materialize(self, t):
         """Value for tensor t, running a pending element-wise chain if needed."""
         v = self.val[t.uid]
+        if isinstance(v, _UpView):                       # a consumer that needs the up-sampled tensor in memory
+            v = self.val[t.uid] = self._realize_up(v)
+        if isinstance(v, _Lazy) and isinstance(v.base, _UpView):
+            v = _Lazy(self._realize_up(v.base), bn=v.bn, relu=v.relu)
         if isinstance(v, _Lazy):
             out = self.new_value(v.base.shape)
             self.emit('eltwise', dict(a=v.base), dict(y=out), dict(op=0, relu=int(v.relu)),
@@ -294,6 +313,39 @@ class Planner:
 
     def lazy_or_value(self, t):
         return self.val[t.uid]
+
+    def _realize_up(self, uv):
+        """Write a virtual up-sampled tensor out after all (once): the stand-alone up-sampling launch."""
+        if uv.full is None:
+            uv.full = self.new_value(uv.shape)
+            self.emit('upsample_add', dict(b=uv.low), dict(y=uv.full), name='upsample')
+        return uv.full
+
+    # ---- R11: UpSampling2D in front of a residual unit is not written out -----------------------------------------
+    def _virtual_upsample_ok(self, node):
+        """True when every reader of this UpSampling2D((2, 2)) output reaches, through BatchNormalization / ReLU only, a
+        plain 1x1 convolution or a separable convolution: those read the half-resolution tensor directly (the 1x1
+        convolution runs BEFORE the up-sampling, the depthwise convolution up-samples on load).  DEEPHAR_UP_COMMUTE=0: off."""
+        t = node.outputs[0]
+        if os.environ.get('DEEPHAR_UP_COMMUTE', '1') == '0' or len(t.shape) < 3 or node.attrs.get('size', (2, 2)) != (2, 2):
+            return False
+        seen, stack, ends = set(), [t], 0
+        while stack:
+            x = stack.pop()
+            if self.out_uids.get(x.uid, 0):
+                return False
+            for n, _ in self.consumers.get(x.uid, []):
+                if n.op in ('bn', 'relu'):
+                    if n.uid not in seen:
+                        seen.add(n.uid)
+                        stack.append(n.outputs[0])
+                elif n.op == 'conv' and (n.attrs['kh'], n.attrs['kw'], n.attrs.get('sh', 1), n.attrs.get('sw', 1)) == (1, 1, 1, 1):
+                    ends += 1
+                elif n.op == 'sepconv' and (n.attrs.get('sh', 1), n.attrs.get('sw', 1)) == (1, 1):
+                    ends += 1
+                else:
+                    return False
+        return ends > 0
 
     # consumers that read a tensor through a (pointer, pixel pitch) view whatever its pitch: they may share a producer's
     # output with ONE concatenate, which then needs no copy (R4b).  Convolutions are NOT in the list (ADVICE r05): no
@@ -536,16 +588,29 @@ class Planner:
             epi['post_relu'] = True
             self.absorbed.add(n.uid)
             t = n.outputs[0]
+        def take(x):
+            """Residual operand x into a free slot: a tensor that only exists at half resolution (R11: the shortcut of an
+            up-scaling unit) becomes the half-resolution second residual, anything else goes to res1, then res2."""
+            v = self.val.get(x.uid)
+            if isinstance(v, _UpView) and v.full is None and epi['res2'] is None and not skinny and len(x.shape) >= 3 and \
+                    x.shape[-3] % 2 == 0 and x.shape[-2] % 2 == 0:
+                epi['res2'], epi['res2_down'] = v.low, True
+                return
+            val = self.materialize(x)
+            if epi['res1'] is None:
+                epi['res1'] = val
+            else:
+                assert epi['res2'] is None
+                epi['res2'] = val
+
         if not epi['post_relu']:
             n = self.sole_consumer(t, 'add')
             if n is not None:
                 others = [x for x in n.inputs if x.uid != t.uid]
                 if len(others) == len(n.inputs) - 1 and 1 <= len(others) <= 2 and \
                         all(self.available(x) for x in others):
-                    vals = [self.materialize(x) for x in others]
-                    epi['res1'] = vals[0]
-                    if len(vals) > 1:
-                        epi['res2'] = vals[1]
+                    for x in sorted(others, key=lambda x: not isinstance(self.val.get(x.uid), _UpView)):
+                        take(x)                 # (a half-resolution operand first: it can only go to the second slot)
                     self.absorbed.add(n.uid)
                     t = n.outputs[0]
             if epi['res2'] is None and not skinny:
@@ -556,14 +621,15 @@ class Planner:
                     epi['res2_down'] = True
                     self.absorbed.update((a2.uid, up.uid))
                     t = a2.outputs[0]
-            if epi['res1'] is not None and epi['res2'] is None and self.split_adds:
+            if (epi['res1'] is None) != (epi['res2'] is None) and self.split_adds:
                 # a second two-operand add behind the first (SPNet: add([residual_unit(x), lateral]), spnet.py:303 on top of
-                # common.py:67): the free residual slot takes it -- (conv + shortcut) + lateral, the reference's order
+                # common.py:67): the free residual slot takes it -- (conv + shortcut) + lateral, the reference's order (with
+                # a half-resolution shortcut in the second slot, R11: (conv + lateral) + shortcut)
                 n2 = self.sole_consumer(t, 'add')
                 if n2 is not None and len(n2.inputs) == 2:
                     other = [x for x in n2.inputs if x.uid != t.uid]
                     if len(other) == 1 and self.available(other[0]):
-                        epi['res2'] = self.materialize(other[0])
+                        take(other[0])
                         self.absorbed.add(n2.uid)
                         t = n2.outputs[0]
             if epi['res2'] is None:
@@ -580,7 +646,38 @@ class Planner:
                             t = a.outputs[0]
         return epi, t
 
+    def _emit_conv_before_upsampling(self, uv, pre_bn, pre_relu, param, a, out_t, name):
+        """R11: conv1x1(UpSampling2D(x)) = UpSampling2D(conv1x1(x)), and so for the BatchNormalization / ReLU around it: the
+        convolution runs on the half-resolution tensor and its result stays a virtual up-sampled tensor (the residual slot
+        of the unit's separable convolution reads it at half resolution)."""
+        low = uv.low
+        t, post_bn, post_relu = out_t, None, False
+        n = self.sole_consumer(t, 'bn')
+        if n is not None:
+            post_bn = n.layers['bn']
+            self.absorbed.add(n.uid)
+            t = n.outputs[0]
+        n = self.sole_consumer(t, 'relu')
+        if n is not None:
+            post_relu = True
+            self.absorbed.add(n.uid)
+            t = n.outputs[0]
+        y = self.new_value(tuple(t.shape[:-3]) + (t.shape[-3] // 2, t.shape[-2] // 2, t.shape[-1]))
+        attrs = dict(kh=1, kw=1, sh=1, sw=1, pt=0, pl=0, Cin=low.C, Cout=a['filters'], K=low.C, pre_relu=int(pre_relu),
+                     post_relu=int(post_relu), up2=0, res2_down=0)
+        params = dict(w=param)
+        if pre_bn is not None:
+            params['pre_bn'] = pre_bn
+        if post_bn is not None:
+            params['post_bn'] = post_bn
+        self.emit('conv', dict(x=low), dict(y=y), attrs, params, name)
+        self.val[t.uid] = _UpView(y, t.shape)
+
     def _emit_conv(self, x, pre_bn, pre_relu, param, a, out_t, name):
+        if isinstance(x, _UpView):
+            if x.full is None and (a['kh'], a['kw'], a.get('sh', 1), a.get('sw', 1)) == (1, 1, 1, 1) and len(out_t.shape) >= 3:
+                return self._emit_conv_before_upsampling(x, pre_bn, pre_relu, param, a, out_t, name)
+            x = self._realize_up(x)
         skinny = len(out_t.shape) >= 3 and split_k_rule(out_t.shape[-3] * out_t.shape[-2], a['kh'] * a['kw'] * x.C,
                                                         a['filters'], x.C, a['kh'], a['kw'])
         epi, final_t = self._epilogue(out_t, skinny)
@@ -620,8 +717,14 @@ class Planner:
         params = dict(w=layer.params[0])
         if pre_bn is not None:
             params['pre_bn'] = pre_bn
+        up_in = 0
+        if isinstance(x, _UpView):               # R11: the depthwise half up-samples on load (dh_dw_args.up_in)
+            if x.full is None and (a.get('sh', 1), a.get('sw', 1)) == (1, 1):
+                x, up_in = x.low, 1
+            else:
+                x = self._realize_up(x)
         self.emit('dwconv', dict(x=x), dict(y=mid),
-                  dict(kh=a['kh'], kw=a['kw'], pt=a['pt'], pl=a['pl'], pre_relu=int(pre_relu)), params,
+                  dict(kh=a['kh'], kw=a['kw'], pt=a['pt'], pl=a['pl'], pre_relu=int(pre_relu), up_in=up_in), params,
                   node.name + '/dw')
         self._emit_conv(mid, None, False, layer.params[1], pw, node.outputs[0], node.name + '/pw')
 
@@ -724,6 +827,9 @@ class Planner:
     def op_upsample(self, node):
         b = self.materialize(node.inputs[0])
         t = node.outputs[0]
+        if self._virtual_upsample_ok(node):      # R11: not written out; its readers take the half-resolution tensor
+            self.val[t.uid] = _UpView(b, t.shape)
+            return
         a_node = self.sole_consumer(t, 'add')
         if a_node is not None and len(a_node.inputs) == 2:
             other = [x for x in a_node.inputs if x.uid != t.uid]

@@ -111,22 +111,25 @@ def normalize_u8(x, lut):
     return y
 
 
-def dwconv2d(x, dw_kernel, pre_scale=None, pre_shift=None, pre_relu=False):
-    """Depthwise conv, stride 1, TF-SAME.  dw_kernel numpy [kh,kw,C,1]."""
+def dwconv2d(x, dw_kernel, pre_scale=None, pre_shift=None, pre_relu=False, up_in=False):
+    """Depthwise conv, stride 1, TF-SAME.  dw_kernel numpy [kh,kw,C,1].  up_in: x is at half resolution and the
+    convolution runs on UpSampling2D((2, 2))(x) without writing it out (dh_dw_args.up_in)."""
     torch = _t()
     _chk(x, pre_scale, pre_shift)
     lib = _lib.load()
     kh, kw, c, _ = dw_kernel.shape
     n, h, w_, cx = x.shape
     assert cx == c
+    if up_in:
+        h, w_ = 2 * h, 2 * w_
     pt, _, _ = same_pad(h, kh, 1)
     pl, _, _ = same_pad(w_, kw, 1)
     wt = torch.from_numpy(np.ascontiguousarray(dw_kernel.reshape(kh * kw, c), np.float32)).to(x.device)
-    y = torch.empty_like(x)
+    y = torch.empty((n, h, w_, c), dtype=torch.float32, device=x.device)
     a = _lib.DwArgs()
     a.x, a.w, a.y, a.pre_scale, a.pre_shift = _p(x), _p(wt), _p(y), _p(pre_scale), _p(pre_shift)
     a.N, a.H, a.W, a.C, a.ldx, a.ldy = n, h, w_, c, c, c
-    a.KH, a.KW, a.PT, a.PL, a.pre_relu = kh, kw, pt, pl, int(pre_relu)
+    a.KH, a.KW, a.PT, a.PL, a.pre_relu, a.up_in = kh, kw, pt, pl, int(pre_relu), int(up_in)
     _lib.check(lib.dh_dwconv2d_f32(C.byref(a), _stream()), 'dh_dwconv2d_f32')
     return y
 

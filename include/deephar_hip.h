@@ -157,6 +157,11 @@ typedef struct dh_dw_args {
   int32_t N, H, W, C, ldx, ldy;
   int32_t KH, KW, PT, PL;
   int32_t pre_relu;
+  int32_t up_in; /* [r06] 1: x is stored at HALF resolution, [N, H/2, W/2, C] (H, W even), and the convolution reads
+                    UpSampling2D((2, 2))(x): input pixel (h, w) = x(h/2, w/2) -- the nearest up-sampling in front of SPNet's
+                    up-scaling unit (deephar/models/common.py:89-108: residual_unit(UpSampling2D(x))) is never written out;
+                    BN / ReLU prologue and zero padding as without it (both act on the up-sampled pixels).  The field
+                    occupies what was tail padding of the struct: a caller that zero-initialises it is unchanged */
 } dh_dw_args;
 int dh_dwconv2d_f32(const dh_dw_args* a, void* stream);
 

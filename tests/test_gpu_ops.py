@@ -249,6 +249,31 @@ def test_dwconv(shape, k, hip_lib, cuda):
            O.depthwise_conv2d(O.relu(t(x) * t(ps) + t(pb)), t(dw)), atol=1e-5, what='dw bn relu')
 
 
+@pytest.mark.parametrize('shape,k', [((2, 16, 16, 384), 5), ((3, 8, 8, 480), 5), ((2, 4, 4, 576), 5), ((2, 32, 32, 96), 5),
+                                     ((1, 22, 16, 32), 5), ((2, 8, 8, 64), 3), ((2, 2, 2, 32), 5), ((1, 3, 5, 20), 3),
+                                     ((2, 4, 6, 6), 5)])
+def test_dwconv_reads_an_upsampled_input(shape, k, hip_lib, cuda):
+    """[r06] dh_dw_args.up_in: the depthwise convolution of UpSampling2D((2, 2))(x) read straight from the half-resolution x
+    (planner rule R11: SPNet's up-scaling unit, common.py:89-108) -- bit for bit the convolution of the explicitly
+    up-sampled tensor, on all three kernels (LDS ring incl. several bands, register strips, generic) and all three
+    prologues; zero padding and the BatchNormalization prologue act on the up-sampled pixels."""
+    from deephar_amd import functional as F
+    rng = np.random.default_rng(sum(shape) + k)
+    x = _rand(rng, shape)
+    dw = _rand(rng, (k, k, shape[3], 1), 1.0 / k)
+    ps, pb = rng.uniform(0.5, 1.5, shape[3]).astype(np.float32), _rand(rng, (shape[3],), 0.3)
+    d = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(cuda)
+    up = np.repeat(np.repeat(x, 2, axis=1), 2, axis=2)
+    for kw in (dict(), dict(pre_relu=True), dict(pre_scale=d(ps), pre_shift=d(pb), pre_relu=True),
+               dict(pre_scale=d(ps), pre_shift=d(pb))):
+        got = F.dwconv2d(d(x), dw, up_in=True, **kw)
+        want = F.dwconv2d(d(up), dw, **kw)
+        assert got.shape == want.shape and torch.equal(got, want), sorted(kw)
+    t = lambda a: torch.from_numpy(a)
+    _close(F.dwconv2d(d(x), dw, pre_scale=d(ps), pre_shift=d(pb), pre_relu=True, up_in=True),
+           O.depthwise_conv2d(O.relu(t(up) * t(ps) + t(pb)), t(dw)), atol=1e-5, what='dw of an up-sampled input')
+
+
 @pytest.mark.parametrize('h,w,c,k', [(32, 32, 64, 5), (16, 16, 32, 5), (8, 8, 32, 3), (40, 64, 32, 3)])
 def test_dwconv_on_channel_slabs(h, w, c, k, hip_lib, cuda):
     """The planner hands the depthwise kernel views into wider tensors (concat slabs): ldx, ldy > C and a channel offset.
