@@ -215,6 +215,10 @@ def assign_streams_tail(plan, deps, items=2, nstreams=2):
     # merged launch order: by simulated start time (a step starts after everything it reads has finished, costs are
     # positive: the order is topological); stream-0 steps keep their relative order
     order = sorted(range(n), key=lambda j: (start[j], j))
+    # (Round 6 tried a helper stream for the SIDE branches of the pose stream -- the 21 1x1 shortcut convolutions, which could
+    #  run beside the depthwise convolution of their unit: 4.49 -> 6.57 ms.  Each such branch needs a dependency INTO the
+    #  origin stream and one back, and a two-way dependency between the queues of a replayed graph costs ~100 us on this
+    #  stack; the one-directional suffix above needs a dozen waits in all.  profiles/r06_helper_stream_experiment.txt)
     return [stream[j] for j in order], order
 
 
