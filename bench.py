@@ -436,14 +436,18 @@ def speed2d_protocol(full_model, args, tune_table):
                     '(two-clip plan warm), fps_per_block_protocol_exact = first timed call after the one-clip warm-up'}
 
 
-def setup_clips(workload, model, per_gpu, world, rank, args, load_tune=None, save_tune=None):
-    """Frame-sharded clip workload: frame stage on T/world frames of every clip -> ONE all-gather -> replicated head."""
+def setup_clips(workload, model, per_gpu, world, rank, args, load_tune=None, save_tune=None, total_clips=None):
+    """Frame-sharded clip workload: frame stage on T/world frames of every clip -> ONE all-gather -> replicated head.
+    Weak scaling: per_gpu * world clips per step (every rank keeps per_gpu * T frames); total_clips: a FIXED number of clips
+    whatever the world (strong scaling: T/world frames of them per rank)."""
     import torch
     from deephar_amd import parallel
     wl = WORKLOADS[workload]
     T = wl['T']
-    clips = per_gpu * world
-    scm = parallel.ShardedClipModel(model, rank=rank, world=world, always_collective=bool(getattr(args, 'force_collective', False)))
+    clips = per_gpu * world if total_clips is None else total_clips
+    scm = parallel.ShardedClipModel(model, rank=rank, world=world, always_collective=bool(getattr(args, 'force_collective', False)),
+                                    overlap=not getattr(args, 'no_overlap', False))
+    LAST_SCM[0] = scm
     fm, hm, info = scm.frame_model, scm.head_model, scm.info
     for mm in (fm, hm):
         mm.executor.use_graph = not args.no_graph
@@ -465,7 +469,7 @@ def setup_clips(workload, model, per_gpu, world, rank, args, load_tune=None, sav
     fbp = fm.executor.bound[clips]
     hbp = hm.executor.bound[clips]
     bound = [(fbp, fm.executor.stream_ptr), (hbp, hm.executor.stream_ptr)]
-    streams = [fm.executor.stream, hm.executor.stream]
+    streams = [fm.executor.stream, hm.executor.stream, _LazyCommStream(scm)]
     flops = fm.plan.total_flops(clips) + hm.plan.total_flops(clips)
     check = lambda: scm.last_outputs[0].cpu().numpy()
     parallelism = 'frame-shard x%d: T/%d frames of %d clips per rank, one packed all-gather [%d, %d, J, %d] fp32, ' \
@@ -574,6 +578,35 @@ def compact_leg(workload, args, rank):
     return leg
 
 
+LAST_SCM = [None]        # the ShardedClipModel of the last setup_clips call (its serial form is timed beside the pipelined one)
+
+
+class _LazyCommStream:
+    """The collective's own stream of a pipelined ShardedClipModel (created at its first step)."""
+
+    def __init__(self, scm):
+        self.scm = scm
+
+    def synchronize(self):
+        if self.scm._comm_stream is not None:
+            self.scm._comm_stream.synchronize()
+
+
+def serial_form_ms(scm, step, streams, pairs, world, steps=10):
+    """[r06] The same clip step with the streams in their SERIAL form (frame stage of step i + 1 behind the collective of
+    step i, deephar_amd/parallel.py): pipelined - serial = what the pipelining hides of the collective and the head stage."""
+    if not scm.overlap:
+        return None
+    scm.synchronize()
+    scm.overlap = False
+    try:
+        dt = timed(step, streams, steps, 2, world, pairs)
+    finally:
+        scm.synchronize()
+        scm.overlap = True
+    return 1e3 * dt / steps
+
+
 def timed(step, streams, steps, warmup, world, pairs=None):
     """W untimed steps, then exactly K steps bracketed by barrier + device synchronisation; max over ranks."""
     import torch
@@ -675,6 +708,23 @@ def dry_run(args, world, rank):
         dist.all_reduce(dt, op=dist.ReduceOp.MAX)
     LAST_TIMED.update(rank_ms_per_step=1e3 * t_local / args.steps, host_enqueue_us_per_step=float(np.mean(us[args.warmup:])))
     per_rank = per_rank_table(world, round(float(np.mean(us[args.warmup:])), 2))
+    # the strong-scaling leg of the contract line (a FIXED clip batch, T / world frames of it per rank), same collective
+    strong = None
+    if world > 1 and 8 % world == 0:
+        tl_s = 8 // world
+        loc = torch.full((clips, tl_s, J, C), float(rank))
+        sbuf = None
+        dist.barrier()
+        s0 = time.perf_counter()
+        for _ in range(args.steps):
+            sbuf = parallel.all_gather_rank_major(loc, world=world, out=sbuf)
+            fr = parallel.frames_view(sbuf).reshape(clips, 8, J, C)
+            assert all(bool((fr[:, r * tl_s:(r + 1) * tl_s] == r).all()) for r in range(world))
+        dist.barrier()
+        sdt = torch.tensor([time.perf_counter() - s0], dtype=torch.float64)
+        dist.all_reduce(sdt, op=dist.ReduceOp.MAX)
+        strong = {'scaling': 'strong', 'clips_per_step': clips, 'frames_per_rank': tl_s,
+                  'value': round(clips * 8 * args.steps / float(sdt), 1), 'unit': 'frames/s'}
     if rank == 0:
         print(json.dumps({'metric': 'dry run of the multi-rank launcher (gloo, CPU): no product measurement', 'per_rank': per_rank,
                           'dry_run': True, 'backend': 'gloo', 'value': round(clips * world * T * args.steps / float(dt), 1),
@@ -682,6 +732,8 @@ def dry_run(args, world, rank):
                           'warmup': args.warmup, 'ms_per_step': round(1e3 * float(dt) / args.steps, 3),
                           'collective_us': round(float(np.mean(us[args.warmup:])), 2), 'higher_is_better': True,
                           'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+                          'per_rank_ms_min_max': [min(r['ms_per_step'] for r in per_rank), max(r['ms_per_step'] for r in per_rank)],
+                          'strong_scaling': strong,
                           'config': {'workload': 'launcher dry run', 'global_batch': clips * world}}))
     if world > 1:
         dist.destroy_process_group()
@@ -718,6 +770,9 @@ def main():
     ap.add_argument('--force-collective', action='store_true',
                     help='clip workloads at N = 1: issue the RCCL all_gather_into_tensor anyway (a world of one would '
                          'short-cut to a view) -- `collective_us` is then the cost of the RCCL call path on one GPU')
+    ap.add_argument('--no-overlap', action='store_true',
+                    help='clip workloads: serial stream form (the frame stage of step i + 1 waits for the collective of step i) '
+                         'instead of the pipelined one (two send / gather slots, the collective on its own stream)')
     ap.add_argument('--dry-run', action='store_true',
                     help='launcher / rendezvous / all-gather / JSON contract on the gloo backend, no HIP device')
     ap.add_argument('--replay-step', type=int, default=None,
@@ -845,9 +900,12 @@ def main():
         return
 
     dt = timed(step, streams, args.steps, args.warmup, world, pairs)
+    serial_ms = None
     if wl['clips']:
         collective_us = round(1e3 * float(np.mean([a.elapsed_time(b) for a, b in pairs])), 2)
     per_rank = per_rank_table(world, collective_us)           # (a collective: every rank calls it)
+    if wl['clips'] and (world > 1 or args.force_collective):
+        serial_ms = serial_form_ms(LAST_SCM[0], step, streams, pairs, world)
 
     # sanity: outputs finite and in range
     pose = check()
@@ -907,10 +965,25 @@ def main():
                                                                              world, rank, args)
         cdt = timed(cstep, cstreams, 10, 2, world, cpairs)
         cpose = ccheck()
-        clip_leg = {'workload': cw['name'], 'value': round(cframes * 10 / cdt, 1), 'unit': 'frames/s',
+        clip_leg = {'workload': cw['name'], 'value': round(cframes * 10 / cdt, 1), 'unit': 'frames/s', 'scaling': 'weak',
                     'steps': 10, 'ms_per_step': round(1e2 * cdt, 3), 'parallelism': cpar, 'rccl_ranks': world,
                     'collective_us': round(1e3 * float(np.mean([a.elapsed_time(b) for a, b in cpairs])), 2),
                     'outputs_finite_in_range': bool(np.all(np.isfinite(cpose)) and cpose.min() >= 0 and cpose.max() <= 1)}
+        if world > 1 or args.force_collective:
+            cser = serial_form_ms(LAST_SCM[0], cstep, cstreams, cpairs, world)
+            if cser is not None:
+                clip_leg['serial_form_ms_per_step'] = round(cser, 3)
+                clip_leg['hidden_by_pipelining_us'] = round(1e3 * cser - 1e5 * cdt, 1)
+        if world > 1:
+            # [r06] ... and the same model under STRONG scaling: the 4 clips of the one-GPU step whatever the world, T / N
+            # frames of them per rank -- the curve that shows what the collective and the replicated head cost
+            del cstep, ccheck
+            sstep, spairs, _, sstreams, sframes, _, scheck, spar, _ = setup_clips('penn_merge', cw['build'](), cw['per_gpu'], world,
+                                                                             rank, args, total_clips=cw['per_gpu'])
+            sdt_ = timed(sstep, sstreams, 10, 2, world, spairs)
+            clip_leg['strong_scaling'] = {'clips_per_step': cw['per_gpu'], 'value': round(sframes * 10 / sdt_, 1), 'unit': 'frames/s',
+                                          'scaling': 'strong', 'steps': 10, 'ms_per_step': round(1e2 * sdt_, 3), 'parallelism': spar,
+                                          'collective_us': round(1e3 * float(np.mean([a.elapsed_time(b) for a, b in spairs])), 2)}
 
     # [r06] ... and, at N = 1, compact legs of the other BASELINE configurations and of the reference's speed protocol
     extra_legs = {}
@@ -951,6 +1024,13 @@ def main():
             out['collective_us'] = collective_us
             out['rccl_ranks'] = world
             out['collective_forced_at_world_1'] = bool(world == 1 and args.force_collective)
+            out['stream_form'] = 'serial' if args.no_overlap else 'pipelined (frame stage of step i + 1 beside the all-gather ' \
+                                 'and head stage of step i: two send / gather slots, collective on its own stream)'
+            if serial_ms is not None:
+                out['serial_form_ms_per_step'] = round(serial_ms, 3)
+                out['hidden_by_pipelining_us'] = round(1e3 * (serial_ms - ms_per_step), 1)
+        ms_ranks = [r['ms_per_step'] for r in per_rank]
+        out['per_rank_ms_min_max'] = [min(ms_ranks), max(ms_ranks)]
         if clip_leg is not None:
             out['frame_sharded_clips'] = clip_leg
         if split_leg is not None:

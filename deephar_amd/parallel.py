@@ -171,18 +171,34 @@ class ShardedClipModel:
     re-ordering pass) -> head stage (hipGraph replay) -> device views of the outputs; only `predict` copies results
     to the host.
 
-    Streams: the frame stage runs on its executor's stream F, the collective on torch's current stream C, the head
-    stage on its executor's stream H.  Per step: F waits for C (the caller's input, and the previous collective's
-    read of the frame arena) and for the event E recorded after H's input copies of the previous step (with one rank
-    H reads the frame arena directly); C waits for F and for E (the gather buffer is re-used); H waits for C.
+    Streams, serial form (`overlap=False`): the frame stage runs on its executor's stream F, the collective on torch's
+    current stream C, the head stage on its executor's stream H.  Per step: F waits for C (the caller's input, and the previous
+    collective's read of the frame arena) and for the event E recorded after H's input copies of the previous step (with one
+    rank H reads the frame arena directly); C waits for F and for E (the gather buffer is re-used); H waits for C -- the
+    frame stage of step i + 1 cannot start before the collective of step i has read the frame arena: the transfer is
+    exposed.
+
+    [r06] Pipelined form (`overlap=True`, the default of the HIP stages): the packed tensor of step i is copied (device to
+    device, on F) into one of TWO send buffers, the collective runs on its own stream K from that buffer into one of two
+    gather buffers, the head stage reads the gather buffer on H.  Slot k = i mod 2: F's copy into send[k] waits for the
+    collective and the head that last used the slot, K waits for F's copy and for the head's input copies of step i - 2,
+    H waits for K.  F never waits for K or H of the step before, so the frame stage of step i + 1 (convolutions: 99 % of
+    a step) runs WHILE the all-gather of step i crosses xGMI and its head stage runs: transfer and head hide behind
+    conv work whenever steps are issued back to back (bench.py, a serving loop).  Results are bit-identical to the serial
+    form; `last_timing` holds the events a caller can read the exposed time from.
 
     frame_fn(x_local [N, T/G, H, W, C]) -> packed [N, T/G, J, Cp] (torch tensor, any device)
     head_fn(list of [N, T, J, c_i])     -> list of arrays / tensors
     may be injected: the CPU tests put oracle stand-ins there to exercise the collective and the bookkeeping with the
     gloo backend."""
 
-    def __init__(self, model, rank=None, world=None, group=None, frame_fn=None, head_fn=None, always_collective=False):
+    def __init__(self, model, rank=None, world=None, group=None, frame_fn=None, head_fn=None, always_collective=False,
+                 overlap=None):
         self.always_collective = bool(always_collective)     # issue the all-gather even for a world of one rank
+        # pipelined streams (class docstring): on for the HIP stages unless asked otherwise; injected CPU stages run serially
+        self.overlap = (frame_fn is None and head_fn is None) if overlap is None else bool(overlap)
+        if self.overlap and (frame_fn is not None or head_fn is not None):
+            raise ValueError('overlap=True needs the HIP stages (it orders HIP streams)')
         if rank is None or world is None:
             import torch.distributed as dist
             rank = dist.get_rank(group) if rank is None else rank
@@ -200,6 +216,11 @@ class ShardedClipModel:
         self.last_outputs = None
         self._gather_buf = None
         self._head_inputs_read = None        # event: the head stage's input copies of the previous step are done
+        # pipelined form: two slots of {send buffer, gather buffer, events}, a stream for the collective, a step counter
+        self._slots = [dict(send=None, gather=None, sent=None, gathered=None, read=None) for _ in range(2)]
+        self._comm_stream = None
+        self._step = 0
+        self.last_timing = None              # (frame stage done, collective start, collective end) events of the last step
 
     # -- default stages on the GPU -----------------------------------------------------------------------
     def _frame_hip(self, x_local):
@@ -224,10 +245,94 @@ class ShardedClipModel:
             self._head_inputs_read = torch.cuda.Event()
         return ex.run_device(tensors, inputs_copied=self._head_inputs_read)
 
+    def _forward_pipelined(self, x_local, events=None):
+        """[r06] One clip batch on the pipelined streams (class docstring): nothing here makes the frame stage of the NEXT
+        call wait for this call's collective or head stage."""
+        import torch
+        info = self.info
+        fx = self.frame_model.executor
+        F = fx.stream
+        cur = torch.cuda.current_stream()
+        if self._comm_stream is None:
+            self._comm_stream = torch.cuda.Stream(device=fx.device)
+        K = self._comm_stream
+        slot = self._slots[self._step % 2]
+        self._step += 1
+        if isinstance(x_local, np.ndarray):
+            x_local = torch.from_numpy(np.ascontiguousarray(x_local, dtype=np.float32)).to(fx.device)
+        ready = torch.cuda.Event()
+        ready.record(cur)                                     # the caller's input (only that: not C's older work)
+        F.wait_event(ready)
+        x_local.record_stream(F)                              # (allocated on the caller's stream, read on F)
+        packed = fx.run_device([x_local])[0]                  # device view inside the frame arena, on F
+        with torch.cuda.stream(F):
+            if slot['send'] is None or tuple(slot['send'].shape) != tuple(packed.shape):
+                slot['send'] = torch.empty(tuple(packed.shape), dtype=packed.dtype, device=packed.device)
+                slot['sent'], slot['gathered'], slot['read'] = torch.cuda.Event(), torch.cuda.Event(), torch.cuda.Event()
+                slot['used'] = False
+            if slot['used']:                                  # the collective / head stage of step i - 2 still read the slot
+                F.wait_event(slot['gathered'])
+                F.wait_event(slot['read'])
+            slot['send'].copy_(packed, non_blocking=True)
+            slot['sent'].record(F)
+        K.wait_event(slot['sent'])
+        if slot['used']:
+            K.wait_event(slot['read'])                        # the gather buffer of the slot is about to be overwritten
+        with torch.cuda.stream(K):
+            if events is not None:
+                events[0].record(K)
+            gathered = all_gather_rank_major(slot['send'], self.group, self.world, out=slot['gather'],
+                                             always=self.always_collective)                     # [G, N, Tl, J, Cp]
+            if self.world > 1 or self.always_collective:
+                slot['gather'] = self._gather_buf = gathered
+            if events is not None:
+                events[1].record(K)
+            slot['gathered'].record(K)
+        slot['used'] = True
+        self.last_timing = (slot['sent'], slot['gathered'])
+        full = frames_view(gathered)
+        n, t = full.shape[0], full.shape[1] * full.shape[2]
+        parts = [full[..., off:off + c] for (_, off, c) in info['cut']]
+        flat = lambda v: v.reshape((n, t) + tuple(v.shape[3:]))
+        outs = [None] * len(self.model.outputs)
+        if self.head_model is not None:
+            hx = self.head_model.executor
+            hx.stream.wait_event(slot['gathered'])
+            head = hx.run_device(parts, inputs_copied=slot['read'])
+            for k, o in zip(info['head_outputs'], head):
+                outs[k] = o
+        else:
+            slot['read'].record(K)
+        if info['passthrough']:
+            # pose tensors that cross the cut unchanged: small contiguous copies made on the head's stream (or K), so that
+            # the slot can be re-used two steps later without the caller holding views into it
+            side = self.head_model.executor.stream if self.head_model is not None else K
+            with torch.cuda.stream(side):
+                for k, ci in info['passthrough'].items():
+                    outs[k] = flat(parts[ci]).contiguous()
+                if self.head_model is not None:
+                    slot['read'].record(side)                 # (re-recorded behind the copies: they read the slot too)
+        self.last_outputs = outs
+        return outs
+
+    def synchronize(self):
+        """Wait for everything forward_device enqueued (the streams it uses are its own)."""
+        import torch
+        for ex in (self.frame_model.executor, self.head_model.executor if self.head_model is not None else None):
+            if ex is not None:
+                ex.stream.synchronize()
+        if self._comm_stream is not None:
+            self._comm_stream.synchronize()
+
     def forward_device(self, x_local, events=None):
         """One clip batch, nothing leaves the device.  `events` = (start, stop) torch events recorded around the
-        collective on the current stream (bench.py: collective_us).  Returns the outputs in model order (pose
-        tensors that pass straight through the cut are small contiguous copies, made after the head was enqueued)."""
+        collective (bench.py: collective_us).  Returns the outputs in model order (pose tensors that pass straight through
+        the cut are small contiguous copies, made after the head was enqueued).  The results live on the stages' own
+        streams: `synchronize()` (or `predict`) before reading them from another stream."""
+        hip = getattr(self.frame_fn, '__func__', None) is ShardedClipModel._frame_hip and \
+            getattr(self.head_fn, '__func__', None) is ShardedClipModel._head_hip
+        if self.overlap and hip:                  # (stand-in stages assigned later run the serial form)
+            return self._forward_pipelined(x_local, events)
         info = self.info
         packed = self.frame_fn(x_local)
         if events is not None:
@@ -278,7 +383,9 @@ class ShardedClipModel:
         info = self.info
         lo = self.rank * info['Tl']
         outs = self.forward_device(np.ascontiguousarray(clips[:, lo:lo + info['Tl']]))
-        if self.head_model is not None and self.head_fn == self._head_hip:
+        if self._comm_stream is not None:
+            self.synchronize()
+        elif self.head_model is not None and self.head_fn == self._head_hip:
             self.head_model.executor.stream.synchronize()
         res = []
         for o in outs:

@@ -36,7 +36,7 @@ def cuda():
 
 
 def pytest_sessionfinish(session, exitstatus):
-    """-m gpu runs: write the per-output parity table (tests/paritylog.py) to gpurun_out/parity_r05.json."""
+    """-m gpu runs: write the per-output parity table (tests/paritylog.py) to gpurun_out/parity_r06.json."""
     try:
         import paritylog
         path = paritylog.dump()

@@ -6,7 +6,7 @@ an fp64 arbiter: every check measures, in the same unit,
     hip_vs_o64 = max|hip - oracle_fp64|     <- the asserted quantity: must be <= tol, no relative escape clause
     o32_vs_o64 = max|oracle_fp32 - oracle_fp64|   (what plain fp32 on the CPU does; recorded, not used as a limit)
     hip_vs_o32 = max|hip - oracle_fp32|     (the quantity north_star names: vs the fp32 reference path)
-and appends them to gpurun_out/parity_r05.json at session end (copied to profiles/ by hand after a GPU run).
+and appends them to gpurun_out/parity_r06.json at session end (copied to profiles/ by hand after a GPU run).
 Records made through `check_conditioned` (SPNet on per-pixel-noise inputs, the stress cases) carry `stress: true`,
 `asserted: false`: they are reported (with their a-priori conditioned tolerance) and summarised apart from the
 flat-tolerance records; `record()` entries (`sweep: true`) are the S-margin sweep of tests/test_gpu_spnet_flat.py.
@@ -90,7 +90,7 @@ def check_conditioned(name, hip, o32, o64, tol_arr, case=None, px=True):
     """STRESS cases only (SPNet on per-pixel-noise inputs with un-fitted heads: multi-modal maps, |logit| up to 100,
     where the CPU fp32 oracle itself is 1-3e-3 px from fp64).  REPORTED, NOT ASSERTED: the record
     carries the three deviations, the a-priori conditioned tolerance (per element, broadcast over the coordinate axis)
-    and `within_apriori`; gpurun_out/parity_r05.json counts how many stress records hold it.  The only assertion is a
+    and `within_apriori`; gpurun_out/parity_r06.json counts how many stress records hold it.  The only assertion is a
     sanity bound (finite, <= 1e-2 px / 1e-2 absolute) against gross breakage.  The 1e-3 px criterion itself is asserted
     flat, on well-conditioned vectors, in tests/test_gpu_spnet_flat.py -- no record anywhere passes through a clause
     relative to the CPU fp32 oracle."""
@@ -131,7 +131,7 @@ def dump(path=None):
     if not RECORDS:
         return None
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    path = path or os.path.join(root, 'gpurun_out', 'parity_r05.json')
+    path = path or os.path.join(root, 'gpurun_out', 'parity_r06.json')
     os.makedirs(os.path.dirname(path), exist_ok=True)
     worst, worst_stress = {}, {}
     for r in RECORDS:

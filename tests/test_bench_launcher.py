@@ -33,6 +33,11 @@ def test_bench_spawns_its_own_ranks():
     assert all(r['ms_per_step'] > 0 and r['collective_us'] > 0 and r['host_enqueue_us_per_step'] > 0 for r in line['per_rank'])
     for key in ('metric', 'unit', 'ms_per_step', 'higher_is_better', 'scaling', 'vs_baseline', 'dtype', 'data', 'config'):
         assert key in line
+    # [r06] per-rank spread and the strong-scaling leg (a fixed clip batch, T / N frames of it per rank) beside the weak one
+    lo, hi = line['per_rank_ms_min_max']
+    assert 0 < lo <= hi
+    assert line['scaling'] == 'weak' and line['strong_scaling']['scaling'] == 'strong'
+    assert line['strong_scaling']['frames_per_rank'] == 4 and line['strong_scaling']['value'] > 0
 
 
 @pytest.mark.timeout(300)

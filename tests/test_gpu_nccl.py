@@ -25,3 +25,5 @@ def test_sharded_clip_model_over_rccl_world_of_one(hip_lib, cuda):
     assert 'nccl world-1 OK: 11 outputs identical' in out.stdout
     # [r05] SPNet-NTU at T = 32 through a real all_gather_into_tensor call (world of one, always_collective)
     assert 'nccl world-1 SPNet-NTU T=32 OK: 12 outputs identical over 3 steps, packed channels 2634' in out.stdout, out.stdout[-1500:]
+    # [r06] the pipelined form: frame stage of step i + 1 beside the all-gather and head stage of step i
+    assert 'nccl world-1 pipelined OK: 5 back-to-back steps identical' in out.stdout, out.stdout[-1500:]

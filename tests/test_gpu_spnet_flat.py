@@ -14,6 +14,7 @@ Configurations at the real 256x256 resolution:
   penn2d_T16      2-D, T = 16 (time_stride 2 branch, spnet.py:100), action on pyramid 2
   penn_shipped    exp/pennaction/eval_penn_multitask.py:36-40: 6 pyramids, actions on 5 and 6, pose_replica=True
   cfg5_ntu_T32    BASELINE.json configs[4]: the NTU model at T = 32
+  speed2d         exp/pennaction/eval_speed2d.py:31-43: 6 pyramids, actions on ALL six, pose_replica=True, T = 8 [r06]
 and the three reference-code goldens 'spnet3d_s', 'spnet2d_s', 'spnet2dr_s' (the reference's own spnet.py run on the
 same kind of vectors, tests/golden/make_reference_golden.py --smooth).
 """
@@ -36,6 +37,8 @@ CONFIGS = {
     'penn2d_T16': (16, 'pa16j2d', 15, 2, [2], 160, False),
     'penn_shipped': (8, 'pa16j2d', 15, 6, [5, 6], 160, True),
     'cfg5_ntu_T32': (32, 'pa17j3d', 60, 2, [1, 2], 192, False),
+    # [r06] the model of the reference's speed protocol (exp/pennaction/eval_speed2d.py:31-43): actions on all six pyramids
+    'speed2d': (8, 'pa16j2d', 15, 6, [1, 2, 3, 4, 5, 6], 160, True),
 }
 SEEDS = (0, 1, 2)        # input seeds {0, 1, 2}; the synthetic weights keep their fixed seed
 NCLIPS = 2               # clips per configuration, predicted in ONE batch (configs[4] is 8 clips per GPU: the other six
@@ -105,7 +108,7 @@ SWEEP_S = (0.02, 0.04, 0.08, 0.15)
 def test_spnet_margin_sweep(name, hip_lib, cuda):
     """How far the engine is from the 1e-3 px bar as the read-out sensitivity S = sum p |g - x| of the fitted heads grows
     (VERDICT r03 item 1b): the same fit at S_TARGET in {0.02, 0.04, 0.08, 0.15}, one clip, fp32 mode.  RECORDED in
-    gpurun_out/parity_r05.json (`margin_sweep`: S asked / measured, worst |hip - o64|, |o32 - o64|, |hip - o32| over every
+    gpurun_out/parity_r06.json (`margin_sweep`: S asked / measured, worst |hip - o64|, |o32 - o64|, |hip - o32| over every
     prediction block); ASSERTED only where the fit reached its target and S <= wellcond.S_MAX = 0.05, the conditioning the
     flat test itself requires (S = 0.02 is not reachable on these maps: a peak between two cells keeps S at half a cell)."""
     from deephar_amd.models import spnet

@@ -48,4 +48,25 @@ if os.environ.get('DEEPHAR_NCCL_CHECK_SPNET', '1') != '0':
             assert np.array_equal(a, np.asarray(b)), (step, float(np.abs(a - np.asarray(b)).max()))
     print('nccl world-1 SPNet-NTU T=32 OK: %d outputs identical over 3 steps, packed channels %d, gather buffer %s' % (
         len(plain), runner.info['packed_channels'], tuple(runner._gather_buf.shape)))
+
+    # [r06] the pipelined streams (two send / gather slots, the collective on its own stream): five steps issued BACK TO
+    # BACK with no synchronisation in between -- step i + 1's frame stage runs while step i's all-gather and head stage are
+    # still in flight -- must give, step for step, the serial form's bits; and the serial form still works
+    assert runner.overlap and runner._comm_stream is not None
+    xd = [torch.from_numpy(xs[i % 3]).to('cuda') for i in range(5)]
+    want = [[np.asarray(o) for o in sp.predict(xs[i % 3], batch_size=1)] for i in range(5)]
+    kept = []
+    H = runner.head_model.executor.stream
+    for i in range(5):
+        outs = runner.forward_device(xd[i])
+        with torch.cuda.stream(H):                 # the outputs are views of the head plan's arena, valid until its next
+            kept.append([o.clone() for o in outs])  # forward: copied out on the head's own stream, no host wait in between
+    runner.synchronize()
+    for i in range(5):
+        for a, b in zip(want[i], kept[i]):
+            assert np.array_equal(a, b.cpu().numpy()), ('pipelined', i)
+    serial = parallel.ShardedClipModel(sp, always_collective=True, overlap=False)
+    for a, b in zip(want[1], serial.predict(xs[1])):
+        assert np.array_equal(a, np.asarray(b))
+    print('nccl world-1 pipelined OK: 5 back-to-back steps identical, 2 slots, collective on its own stream')
 dist.destroy_process_group()
