@@ -234,6 +234,8 @@ def cpu_baseline(model, workload, blocks):
 def kernel_name(s):
     """The template instantiation a conv step launches, spelled as rocprofv3 demangles it."""
     cfg = s.attrs.get('tile_cfg', -1)
+    if s.attrs.get('grouped'):
+        return 'conv_dw_group_kernel (1x1 shortcut conv + the unit\'s depthwise conv in one launch)'
     if s.attrs.get('split_k'):
         return 'conv_splitk_kernel'
     if s.attrs.get('first_layer'):
@@ -493,7 +495,8 @@ def setup_frame_workload(model, n, T, args, world, rank, load_tune=None, save_tu
         shape, cfg = args.force_cfg.split(':')
         mkn = tuple(int(v) for v in shape.split(','))
         for i, (fn, cargs, st) in enumerate(bp.calls):
-            if st.kind == 'conv' and not st.attrs.get('split_k') and not st.attrs.get('first_layer'):
+            if st.kind == 'conv' and not st.attrs.get('split_k') and not st.attrs.get('first_layer') and \
+                    not st.attrs.get('grouped'):
                 a0 = cargs[0]._obj
                 if (a0.N * a0.OH * a0.OW, a0.K, a0.Cout) == mkn:
                     bp.calls[i] = (fn, (cargs[0], int(cfg)), st)

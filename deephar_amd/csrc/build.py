@@ -15,7 +15,7 @@ ROOT = os.path.dirname(os.path.dirname(HERE))
 INCLUDE = os.path.join(ROOT, "include")
 SOURCES = ["conv_igemm.hip", "gemm1x1.hip", "gemm1x1s.hip", "conv_splitk.hip", "conv_halo.hip", "conv_stem.hip", "spatial.hip", "decoder.hip",
            "capi.hip", "plan.hip"]
-HEADERS = [os.path.join(HERE, "dh_kernels.h"), os.path.join(HERE, "conv_common.h"),
+HEADERS = [os.path.join(HERE, "dh_kernels.h"), os.path.join(HERE, "conv_common.h"), os.path.join(HERE, "dw_lds.h"),
            os.path.join(INCLUDE, "deephar_hip.h")]
 LIB = os.path.join(HERE, "libdeephar_hip.so")
 OBJDIR = os.path.join(HERE, "build")

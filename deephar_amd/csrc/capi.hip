@@ -113,6 +113,16 @@ int dh_conv2d_f32(const dh_conv_args* a, int tile_cfg, void* stream) {
   return launch_conv_igemm(*a, tile_cfg, S(stream));
 }
 
+int dh_conv2d_dw_group_f32(const dh_conv_args* a, const dh_dw_args* d, void* stream) {
+  if (a == nullptr || d == nullptr || a->x == nullptr || a->w == nullptr || a->y == nullptr || d->x == nullptr ||
+      d->w == nullptr || d->y == nullptr)
+    return DH_EINVAL;
+  if ((a->pre_scale == nullptr) != (a->pre_shift == nullptr) || (a->post_scale == nullptr) != (a->post_shift == nullptr) ||
+      (d->pre_scale == nullptr) != (d->pre_shift == nullptr))
+    return DH_EINVAL;
+  return launch_conv_dw_group(*a, *d, S(stream));
+}
+
 int dh_normalize_u8_f32(const uint8_t* x, const float* lut, float* y, int64_t n_pixels, int C, void* stream) {
   if (x == nullptr || lut == nullptr || y == nullptr) return DH_EINVAL;
   return launch_normalize_u8(x, lut, y, n_pixels, C, S(stream));

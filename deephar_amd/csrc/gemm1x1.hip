@@ -18,6 +18,7 @@
 #include <algorithm>
 
 #include "conv_common.h"
+#include "dw_lds.h"
 
 namespace dh {
 namespace {
@@ -87,8 +88,12 @@ __device__ __forceinline__ void fetch_frags(const unsigned (&a_addr)[TM][4], uns
 // KXK: the same kernel as an implicit GEMM over a K x K (strided, zero-padded) convolution whose Cin is a multiple
 // of 32: K-step kt covers 32 channels of ONE filter tap, so each staged row is still one contiguous 128-byte run -- of
 // the tap's input pixel, or of a page of zeros when the tap falls into the padding (ReLU-on-load keeps zeros zero).
+// The kernel body as a device function: `block` of `nblocks` is the work-group's index among the GEMM work-groups (the
+// kernel's blockIdx.x / gridDim.x, or its share of a grouped launch: conv_dw_group_kernel below), `smem` the work-group's
+// dynamic LDS; threads 0 .. WM * WN * 64 - 1 run it.
 template <int WM, int WN, int TM, int TN, bool UP2, bool RELU, bool KXK = false, bool PRE = false>
-__global__ __launch_bounds__(WM* WN * 64, 2) void gemm1x1_kernel(const ConvArgs p, const int epi_vec) {
+__device__ __forceinline__ void gemm1x1_body(const ConvArgs& p, const int epi_vec, const int block, const int nblocks,
+                                             float* const smem) {
   static_assert(!(PRE && (KXK || UP2)), "the BN prologue is built for the plain pointwise form");
   constexpr int NT = WM * WN * 64;
   constexpr int BM = WM * TM * 32;
@@ -98,8 +103,6 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void gemm1x1_kernel(const ConvArgs 
   constexpr int STAGE = BM * BK + BK * BN;  // floats per stage
   static_assert(BM * 8 % NT == 0 && (8 * BN) % NT == 0, "tile/thread mismatch");
 
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;
@@ -108,7 +111,7 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void gemm1x1_kernel(const ConvArgs 
 
   const int M = p.N * p.OH * p.OW;
   const int tiles_n = (p.Cout + BN - 1) / BN;
-  const int tile = xcd_tile(blockIdx.x, gridDim.x);
+  const int tile = xcd_tile(block, nblocks);
   const int m0 = (tile / tiles_n) * BM;
   const int n0 = (tile % tiles_n) * BN;
 
@@ -289,6 +292,35 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void gemm1x1_kernel(const ConvArgs 
   conv_epilogue<WM, WN, TM, TN, UP2, true>(p, acc, smem, m0, n0, M, epi_vec, pre);
 }
 
+template <int WM, int WN, int TM, int TN, bool UP2, bool RELU, bool KXK = false, bool PRE = false>
+__global__ __launch_bounds__(WM* WN * 64, 2) void gemm1x1_kernel(const ConvArgs p, const int epi_vec) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  gemm1x1_body<WM, WN, TM, TN, UP2, RELU, KXK, PRE>(p, epi_vec, (int)blockIdx.x, (int)gridDim.x, smem);
+}
+
+// [r06] Grouped launch for the LATENCY regime: the 1x1 shortcut convolution of a residual unit and the depthwise convolution
+// of its main path (deephar/models/common.py:25-67: `shortcut = conv2d(relu(BN(x)))` beside `sepconv2d(relu(BN(x)))`) read
+// the same tensor and do not depend on each other, but as two nodes of a one-stream graph they run one after the other, and
+// a node costs ~5 us plus its work however small (profiles/r06_speed2d_timeline.md); putting one of them on another stream
+// costs more than it saves (profiles/r06_helper_stream_experiment.txt).  Here ONE launch runs both: work-groups
+// [0, nb_conv) are the GEMM's, the rest the depthwise kernel's (dw_lds.h), each running exactly the code of its stand-alone
+// kernel -- same bits.  Work-groups are 256 threads; the waves a body does not need end at once (s_barrier counts only the
+// waves still alive).
+template <int WM, bool PRE, bool RELU, int KS, int DNT, int MAXT, int MAXN, bool AFF, bool DRELU>
+__global__ __launch_bounds__(256) void conv_dw_group_kernel(const ConvArgs pc, const int epi_vec, const int nb_conv,
+                                                            const DwArgs pd, const int tw, const int rows,
+                                                            const int twh_magic) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  if ((int)blockIdx.x < nb_conv) {
+    if (threadIdx.x < WM * 64)
+      gemm1x1_body<WM, 1, 1, 1, false, RELU, false, PRE>(pc, epi_vec, (int)blockIdx.x, nb_conv, smem);
+  } else {
+    if (threadIdx.x < DNT)
+      dwl::dwconv_lds_body<KS, DNT, MAXT, MAXN, AFF, DRELU>(pd, tw, rows, twh_magic, (int)blockIdx.x - nb_conv,
+                                                            reinterpret_cast<float4*>(smem));
+  }
+}
+
 constexpr int kMaxPreKp = 4096;    // BN prologue: scale + shift tables of at most 2 x 16 KB in LDS
 
 template <int WM, int WN, int TM, int TN, bool UP2, bool RELU, bool KXK = false, bool PRE = false>
@@ -349,6 +381,58 @@ bool gemm1x1_eligible(const ConvArgs& a) {
   const bool pre_ok = a.pre_scale == nullptr || (pointwise && !a.up2 && a.w_split == 0 && a.Kp <= kMaxPreKp);
   const bool fits32 = (long long)a.N * a.H * a.W * a.ldx * 4 <= 0xf0000000LL;      // 32-bit buffer offsets
   return aligned && pre_ok && fits32 && (pointwise || kxk);
+}
+
+bool conv_is_skinny(const ConvArgs& a);
+bool conv_stem_eligible(const ConvArgs& a);
+
+namespace {
+
+template <int WM, int KS, int DNT, int MAXT, int MAXN>
+int launch_group(const ConvArgs& a, int epi, const DwArgs& d, const dwl::DwLdsGeom& g, hipStream_t s) {
+  constexpr int BM = WM * 32, BN = 32;
+  const long long M = (long long)a.N * a.OH * a.OW;
+  const long long tiles = ((M + BM - 1) / BM) * ((a.Cout + BN - 1) / BN);
+  if (tiles <= 0 || tiles + (long long)g.blocks > 0x7fffffffLL) return DH_EINVAL;
+  constexpr int kStage = 2 * (BM * BK + BK * BN), kEpi = WM * 32 * (32 + 4);
+  const size_t lds_conv = (size_t)std::max(kStage > kEpi ? kStage : kEpi, kStage + 2 * a.Kp) * sizeof(float);
+  const size_t lds = std::max(lds_conv, g.lds);
+  auto kern = conv_dw_group_kernel<WM, true, true, KS, DNT, MAXT, MAXN, true, true>;
+  static LdsLimit lim;
+  lim.raise((const void*)kern, 160 * 1024);
+  if (lds > 160 * 1024) return DH_EUNSUPPORTED;
+  hipLaunchKernelGGL(kern, dim3((unsigned)tiles + g.blocks), dim3(256), lds, s, a, epi, (int)tiles, d, g.tw, g.rows,
+                     65536 / (g.tw + KS - 1) + 1);
+  return check_launch();
+}
+
+}  // namespace
+
+// The 1x1 shortcut convolution `a` (BatchNormalization + ReLU prologue, fp32 tap-major weights, LDS-DMA GEMM family) and the
+// 5x5 depthwise convolution `d` (BatchNormalization + ReLU prologue, LDS-tiled kernel) in one launch; DH_EUNSUPPORTED for
+// anything else -- the caller then launches the two on their own, with the same result bits.
+int launch_conv_dw_group(const ConvArgs& a, const DwArgs& d, hipStream_t s) {
+  if (a.N <= 0 || a.Cin <= 0 || a.Cout <= 0 || a.OH <= 0 || a.OW <= 0 || d.N <= 0 || d.C <= 0) return DH_EINVAL;
+  if (a.Kp % BK != 0 || a.Np % 32 != 0 || a.Kp < a.K || a.Np < a.Cout || a.K != a.KH * a.KW * a.Cin) return DH_EINVAL;
+  const bool pointwise = a.KH == 1 && a.KW == 1 && a.SH == 1 && a.SW == 1 && a.PT == 0 && a.PL == 0 && a.H == a.OH && a.W == a.OW;
+  if (!pointwise || a.up2 || a.y_pool != nullptr || a.x_u8 || a.w_split || a.pre_scale == nullptr || !a.pre_relu ||
+      a.Kp > kMaxPreKp || !gemm1x1_eligible(a) || conv_is_skinny(a) || conv_stem_eligible(a))
+    return DH_EUNSUPPORTED;
+  if (a.res2_down && (a.res2 == nullptr || (a.OH & 1) || (a.OW & 1))) return DH_EINVAL;
+  dwl::DwLdsGeom g;
+  if (d.KW != 5 || d.pre_scale == nullptr || !d.pre_relu || !dwl::dw_lds_geometry(d, g)) return DH_EUNSUPPORTED;
+  if (d.up_in && ((d.H & 1) || (d.W & 1))) return DH_EINVAL;
+  auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
+  const int epi0 = (a.Cout % 4 == 0) && (a.ldy % 4 == 0) && al16(a.y) && (a.res1 == nullptr || (a.ldr1 % 4 == 0 && al16(a.res1))) &&
+                   (a.res2 == nullptr || (a.ldr2 % 4 == 0 && al16(a.res2))) &&
+                   (a.post_scale == nullptr || (al16(a.post_scale) && al16(a.post_shift)));
+  const int epi = epi_with_direct(a, epi0);
+  const long long M = (long long)a.N * a.OH * a.OW;
+  if (M > 0x7fffffffLL) return DH_EINVAL;
+  // (all tilings of the family give the same bits: the group picks its own -- 128-row tiles once they fill the chip)
+  const bool wide = ((M + 127) / 128) * ((a.Cout + 31) / 32) >= 256;
+  if (g.nt == 256) return wide ? launch_group<4, 5, 256, 5, 10>(a, epi, d, g, s) : launch_group<2, 5, 256, 5, 10>(a, epi, d, g, s);
+  return wide ? launch_group<4, 5, 64, 6, 12>(a, epi, d, g, s) : launch_group<2, 5, 64, 6, 12>(a, epi, d, g, s);
 }
 
 int launch_gemm1x1(const ConvArgs& a, int cfg, int epi, hipStream_t s) {

@@ -184,6 +184,8 @@ class BoundPlan:
                     self.npre += 1
         for step in plan.steps:
             self._bind(step)
+        self.grouped = 0      # pairs of launches merged into one (group_launches: latency regime only)
+        self.noop_calls = set()   # indices of `calls` whose work moved into an earlier, grouped launch
 
     def weight_layout(self, args):
         """dh_conv_args.w_split of a conv step: 1 = split-bf16 (plan.gemm_precision == 'bf16x3' and the library takes the
@@ -462,6 +464,51 @@ class BoundPlan:
             _lib.check(lib.dh_event_record(ev, st), 'join record')
             _lib.check(lib.dh_stream_wait_event(stream_ptr, ev), 'join wait')
 
+    # ---- grouped launches (latency regime) ------------------------------------------------------------------------
+    GROUP_MAX_ROWS = 8192           # conv rows (pixels of the bound batch) up to which a pair is merged
+    GROUP_MAX_DW_ELEMS = 1 << 23    # ... and depthwise elements
+
+    def group_launches(self, stream_ptr):
+        """[r06] Merge every (1x1 shortcut convolution, depthwise convolution) pair of a pre-activation residual unit that is
+        launched back to back on one stream, reads the same tensor and is small enough to be bound by the cost of a node
+        rather than by its work into ONE launch (dh_conv2d_dw_group_f32: bit-identical, the work-groups of one grid run
+        either kernel's code).  The depthwise entry of `calls` stays as a no-op so that step indices (event waits, per-step
+        profiles) keep their meaning.  DEEPHAR_GROUP_LAUNCHES=0 switches it off.  Returns the number of pairs merged."""
+        if os.environ.get('DEEPHAR_GROUP_LAUNCHES', '1') == '0' or self.grouped:
+            return self.grouped
+        lib = self.lib
+        for i in range(self.npre, len(self.calls) - 1):
+            fc, ac, sc = self.calls[i]
+            # the next launch ON THE SAME STREAM (a multi-stream plan interleaves the streams in launch order): the pair is
+            # consecutive there, so running the depthwise conv at the shortcut's place moves it past nothing it is ordered
+            # with -- it waits for no event of its own (checked), and what it writes was planned to be free from here on
+            j = next((k for k in range(i + 1, len(self.calls)) if self.calls[k][2].stream == sc.stream), None)
+            if j is None:
+                continue
+            fd, ad, sd = self.calls[j]
+            if sc.kind != 'conv' or sd.kind != 'dwconv' or sd.wait or i in self.noop_calls or fc is lib.dh_conv2d_dw_group_f32:
+                continue
+            xc, xd = sc.ins['x'], sd.ins['x']
+            if xc.buf is not xd.buf or any(v is not None and v.buf is sc.outs['y'].buf for v in sd.ins.values()):
+                continue                               # not the same input, or the depthwise conv reads the conv's result
+            ca, da = ac[0]._obj, ad[0]._obj
+            if ca.N * ca.OH * ca.OW > self.GROUP_MAX_ROWS or da.N * da.H * da.W * da.C > self.GROUP_MAX_DW_ELEMS:
+                continue
+            if lib.dh_conv2d_dw_group_f32(ac[0], ad[0], stream_ptr) != 0:      # (a real launch: the pair's own outputs)
+                continue
+            sc.attrs['grouped'] = True                 # (for bench.py's kernel names: the plan's steps are shared by every
+            self.calls[i] = (lib.dh_conv2d_dw_group_f32, (ac[0], ad[0]), sc)      # batch size it is bound to -- what counts
+            self.calls[j] = (_noop_launch, (), sd)                                 # for execution is `calls` / `noop_calls`)
+            self.noop_calls.add(j)
+            self.grouped += 1
+        if self.grouped and self.graph is not None:
+            if self.plan.nstreams > 1:
+                _GRAPH_GRAVEYARD.append(self.graph)
+            else:
+                lib.dh_graph_destroy(self.graph)
+            self.graph = None
+        return self.grouped
+
     def capture(self, stream_ptr):
         """Capture the launch sequence into a hipGraph.  -> False (nothing captured; the caller launches eagerly) when
         this is a multi-stream plan and the process already holds MAX_MULTISTREAM_GRAPHS such graph execs: they can only
@@ -620,6 +667,11 @@ class BoundPlan:
             pass
 
 
+def _noop_launch(*_args):
+    """Placeholder of a launch that was merged into the one before it (BoundPlan.group_launches)."""
+    return 0
+
+
 _GRAPH_GRAVEYARD = []
 # multi-stream graph execs ever created by this process (live + parked): capped, see BoundPlan.capture.  One-stream
 # plans (the default, Model.num_streams = 1) destroy their graphs and are not counted.
@@ -672,6 +724,7 @@ class Executor:
                 bp = BoundPlan(self.plan, n, self.store, self.device, u8_norm=u8_norm)
                 if self.autotune:
                     bp.autotune(self.stream_ptr, self.tune_table)
+                bp.group_launches(self.stream_ptr)
             self.bound[key] = bp
             while len(self.bound) > self.max_bound:         # dataset tails / box-refinement loops bind many sizes:
                 old = next(iter(self.bound))                # drop the least recently used arena + graph

@@ -84,22 +84,34 @@ def split_k_rule(out_pixels, K, cout, cin, kh=1, kw=1):
 
 
 class ConcatParam:
-    """Several convolution kernels with equal [kh, kw, Cin] side by side along Cout: the weight a horizontally merged
-    convolution (rule R10) reads.  Looks like a graph.Param to the weight store: `value` is assembled on demand, `version`
-    moves whenever a part is set."""
+    """Several convolution kernels over the same Cin side by side along Cout: the weight a horizontally merged convolution
+    (rule R10) reads.  Looks like a graph.Param to the weight store: `value` is assembled on demand, `version` moves whenever
+    a part is set.  [r06] The parts may have different (odd) extents: each is centred inside the largest [kh, kw] window,
+    the taps around it are zero -- a 3x1 and a 3x3 kernel beside a 3x5 one (rule R10b)."""
     role = 'conv'
 
     def __init__(self, parts):
         self.parts = list(parts)
         self.key = ' + '.join(p.key for p in self.parts)
         self.name = 'kernel'
-        self.shape = tuple(self.parts[0].shape[:-1]) + (sum(p.shape[-1] for p in self.parts),)
+        self.kh = max(p.shape[0] for p in self.parts)
+        self.kw = max(p.shape[1] for p in self.parts)
+        assert all((self.kh - p.shape[0]) % 2 == 0 and (self.kw - p.shape[1]) % 2 == 0 and p.shape[2] == self.parts[0].shape[2]
+                   for p in self.parts)
+        self.shape = (self.kh, self.kw, self.parts[0].shape[2], sum(p.shape[-1] for p in self.parts))
 
     @property
     def value(self):
         if any(p.value is None for p in self.parts):
             return None
-        return np.ascontiguousarray(np.concatenate([p.value for p in self.parts], axis=-1))
+        out = np.zeros(self.shape, np.float32)
+        off = 0
+        for p in self.parts:
+            v = np.asarray(p.value, np.float32)
+            t, l = (self.kh - v.shape[0]) // 2, (self.kw - v.shape[1]) // 2
+            out[t:t + v.shape[0], l:l + v.shape[1], :, off:off + v.shape[3]] = v
+            off += v.shape[3]
+        return out
 
     @property
     def version(self):
@@ -424,15 +436,29 @@ class Planner:
         inside the family rule of their parts and carry no epilogue.)  DEEPHAR_MERGE_HEADS=0 switches it off."""
         if os.environ.get('DEEPHAR_MERGE_HEADS', '1') == '0':
             return
-        same = ('kh', 'kw', 'sh', 'sw', 'pt', 'pl', 'Cin', 'K', 'pre_relu', 'post_relu', 'up2', 'res2_down')
+        same = ('sh', 'sw', 'Cin', 'pre_relu', 'post_relu', 'up2', 'res2_down')
 
         def mergeable(a, b):
             if a.kind != 'conv' or b.kind != 'conv' or set(a.ins) != {'x'} or set(b.ins) != {'x'} or \
                     set(a.outs) != {'y'} or set(b.outs) != {'y'}:
                 return False
-            if any(a.attrs.get(k) != b.attrs.get(k) for k in same) or a.attrs['kh'] != 1 or a.attrs['kw'] != 1 or \
+            if any(a.attrs.get(k) != b.attrs.get(k) for k in same) or \
                     a.attrs['up2'] or a.attrs['res2_down'] or a.attrs.get('sh', 1) != 1 or a.attrs.get('sw', 1) != 1:
                 return False
+            pointwise = all(st.attrs['kh'] == 1 and st.attrs['kw'] == 1 for st in (a, b))
+            if not pointwise:
+                # [r06, R10b] K x K siblings of one tensor -- the three bare convolutions over the (T, J) plane that open
+                # every action head, spnet.py:109-112: 3x1, 3x3, 3x5 into one concatenation -- run as ONE convolution with
+                # the largest window, the smaller kernels centred in it between zero taps (ConcatParam): every product
+                # beside the part's own taps is an exact zero, the taps keep their relative order, so each output column
+                # still sees its own chain of fused multiply-adds.  Odd kernels under symmetric 'SAME' padding only, on the
+                # general kernel (Cin not a multiple of 16: the K x K families order K by chunks of channels).
+                for st in (a, b):
+                    if st.attrs['kh'] % 2 == 0 or st.attrs['kw'] % 2 == 0 or st.attrs['pt'] != st.attrs['kh'] // 2 or \
+                            st.attrs['pl'] != st.attrs['kw'] // 2 or st.attrs['Cin'] % 16 == 0:
+                        return False
+                if os.environ.get('DEEPHAR_MERGE_KXK', '1') == '0':
+                    return False
             if set(a.params) - {'w', 'pre_bn'} or set(b.params) - {'w', 'pre_bn'} or \
                     a.params.get('pre_bn') is not b.params.get('pre_bn'):
                 return False
@@ -442,8 +468,10 @@ class Planner:
             if ya.buf is not yb.buf or ya.ld != yb.ld or ya.shape[:-1] != yb.shape[:-1] or ya.coff + ya.C != yb.coff:
                 return False
             px = ya.shape[-3] * ya.shape[-2] if len(ya.shape) >= 3 else 1
-            fam = lambda c: split_k_rule(px, a.attrs['K'], c, a.attrs['Cin'], a.attrs['kh'], a.attrs['kw'])
-            return fam(ya.C) == fam(yb.C) == fam(ya.C + yb.C)
+            kh, kw = max(a.attrs['kh'], b.attrs['kh']), max(a.attrs['kw'], b.attrs['kw'])
+            fam = lambda st, c, h, w_: split_k_rule(px, h * w_ * st.attrs['Cin'], c, st.attrs['Cin'], h, w_)
+            return fam(a, ya.C, a.attrs['kh'], a.attrs['kw']) == fam(b, yb.C, b.attrs['kh'], b.attrs['kw']) == \
+                fam(a, ya.C + yb.C, kh, kw)
 
         steps = self.plan.steps
         i = 0
@@ -464,8 +492,12 @@ class Planner:
             for st in (first, second):
                 w = st.params['w']
                 parts += w.parts if isinstance(w, ConcatParam) else [w]
-            params = dict(first.params, w=ConcatParam(parts))
-            attrs = dict(first.attrs, Cout=ya.C + yb.C)
+            wcat = ConcatParam(parts)
+            params = dict(first.params, w=wcat)
+            attrs = dict(first.attrs, Cout=ya.C + yb.C, kh=wcat.kh, kw=wcat.kw, pt=wcat.kh // 2, pl=wcat.kw // 2,
+                         K=wcat.kh * wcat.kw * first.attrs['Cin'])
+            if (wcat.kh, wcat.kw) == (1, 1):
+                attrs.update(pt=first.attrs['pt'], pl=first.attrs['pl'])
             merged = Step('conv', dict(first.ins), dict(y=y), attrs, params, '%s+%s' % (first.name, second.name))
             del steps[j]
             steps[i] = merged

@@ -28,7 +28,7 @@ MAGIC, VERSION = b'DHPL', 2
 FUNCTIONS = ['dh_conv2d_f32', 'dh_dwconv2d_f32', 'dh_pool2d_f32', 'dh_upsample2x_add_f32', 'dh_eltwise_f32',
              'dh_softargmax2d_f32', 'dh_context_aggregation_f32', 'dh_depth_means_f32', 'dh_softargmax1d_f32',
              'dh_kronecker_f32', 'dh_global_maxmin_softmax_f32', 'dh_copy_channels_f32', 'dh_zeropad2d_f32',
-             'dh_depth_from_maps_f32', 'dh_softargmax2d_context_f32', 'dh_normalize_u8_f32']
+             'dh_depth_from_maps_f32', 'dh_softargmax2d_context_f32', 'dh_normalize_u8_f32', 'dh_conv2d_dw_group_f32']
 ARENA, WEIGHTS, BYTES = 1, 2, 3
 
 
@@ -105,19 +105,26 @@ def dump_plan(model, batch, u8_norm=None):
     by_addr = {C.cast(getattr(lib, n), C.c_void_p).value: n for n in FUNCTIONS}
     reg = _Regions(bp)
     steps = []
-    for fn, args, step in bp.calls:
+    for idx, (fn, args, step) in enumerate(bp.calls):
+        if idx in bp.noop_calls:                              # merged into an earlier launch (BoundPlan.group_launches)
+            continue
         name = by_addr.get(C.cast(fn, C.c_void_p).value)
         if name is None:
             raise ValueError('step %s (%s) has no serialised form' % (step.kind, step.name))
         sig = _lib.SIGNATURES[name][1][:-1]                 # without the trailing stream
         if len(sig) and isinstance(getattr(sig[0], '_type_', None), type) and issubclass(sig[0]._type_, C.Structure):
-            obj = args[0]._obj
-            raw = bytearray(bytes(obj))
-            for fname, ftype in obj._fields_:
-                if _is_ptr_type(ftype):
-                    off = getattr(type(obj), fname).offset
-                    raw[off:off + 8] = struct.pack('<Q', reg.tag(getattr(obj, fname)))
-            payload = bytes(raw) + _scalars(sig[1:], args[1:], reg)
+            payload, nstruct = b'', 0
+            while nstruct < len(sig) and isinstance(getattr(sig[nstruct], '_type_', None), type) and \
+                    issubclass(sig[nstruct]._type_, C.Structure):     # (dh_conv2d_dw_group_f32 takes two structs)
+                obj = args[nstruct]._obj
+                raw = bytearray(bytes(obj))
+                for fname, ftype in obj._fields_:
+                    if _is_ptr_type(ftype):
+                        off = getattr(type(obj), fname).offset
+                        raw[off:off + 8] = struct.pack('<Q', reg.tag(getattr(obj, fname)))
+                payload += bytes(raw)
+                nstruct += 1
+            payload += _scalars(sig[nstruct:], args[nstruct:], reg)
         else:
             payload = _scalars(sig, args, reg)
         steps.append(struct.pack('<II', names[name], len(payload)) + payload)

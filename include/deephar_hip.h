@@ -165,6 +165,15 @@ typedef struct dh_dw_args {
 } dh_dw_args;
 int dh_dwconv2d_f32(const dh_dw_args* a, void* stream);
 
+/* [r06] The two independent first layers of a pre-activation residual unit in ONE launch (deephar/models/common.py:25-67:
+ * `shortcut = conv2d(relu(BN(x)), out, (1, 1))` beside `sepconv2d(relu(BN(x)), ...)`, whose depthwise half is `dw`): the
+ * 1x1 convolution `conv` (BatchNormalization + ReLU prologue, w_split = 0, any epilogue of dh_conv_args but up2 / y_pool)
+ * and the 5x5 depthwise convolution `dw` (BatchNormalization + ReLU prologue).  Work-groups of the one grid run either
+ * kernel's own code, so the results are bit for bit those of dh_conv2d_f32 + dh_dwconv2d_f32; what is saved is one
+ * dependent launch (~5 us plus the shorter of the two kernels) -- the latency regime of a couple of clips per call
+ * (exp/pennaction/eval_speed2d.py).  DH_EUNSUPPORTED for any pair outside that description (call the two entry points). */
+int dh_conv2d_dw_group_f32(const dh_conv_args* conv, const dh_dw_args* dw, void* stream);
+
 /* MaxPooling2D (reception.py:74,86,108,115; layers.py:92-97), padding cells ignored;
  * mode 1 = layers.max_min_pooling (layers.py:411-425): maxpool(x) - maxpool(-x) */
 typedef struct dh_pool_args {

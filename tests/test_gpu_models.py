@@ -176,8 +176,9 @@ def test_heat_map_head_rules_are_bit_identical(hip_lib, cuda, monkeypatch):
         monkeypatch.setenv('DEEPHAR_MERGE_HEADS', '1')
         monkeypatch.setenv('DEEPHAR_CONCAT_SHARED', '1')
         m, _, _, _ = _spnet(4, layout, nact, 2, [1, 2], 160, replica=rep, res=128)
-        merged = [s for s in m.plan.steps if s.kind == 'conv' and '+' in (s.name or '')]
-        assert len(merged) == 5 and len(m.plan.steps) == nbase - 10          # five heads: one copy and one conv less each
+        merged = [s for s in m.plan.steps if s.kind == 'conv' and '+' in (s.name or '') and 'heatmaps' in s.name]
+        # five heads: one copy and one conv less each; [r06] the switch also governs rule R10b (two launches less per action head)
+        assert len(merged) == 5 and len(m.plan.steps) == nbase - 10 - 12
         for a, b in zip(want, m.predict(clips, batch_size=2)):
             assert np.array_equal(a, b)
         # a weight of ONE part changed after the first predict: the merged launch must see it
@@ -186,6 +187,63 @@ def test_heat_map_head_rules_are_bit_identical(hip_lib, cuda, monkeypatch):
         next(l for n in base._nodes for l in n.layers.values() if l.name == layer.name).params[0].set(layer.params[0].value)
         for a, b in zip(base.predict(clips, batch_size=2), m.predict(clips, batch_size=2)):
             assert np.array_equal(a, b)
+
+
+def test_merged_kxk_siblings_are_bit_identical(hip_lib, cuda, monkeypatch):
+    """[r06] Planner rule R10b: the three bare convolutions over the (T, J) plane that open every action head (spnet.py:
+    109-112: 3x1, 3x3, 3x5 of one tensor, concatenated) as ONE 3x5 convolution whose smaller kernels sit centred between
+    zero taps -- two launches fewer per head, not one bit moved (the extra products are exact zeros, the taps keep their
+    order); weights set on one part after the first predict reach the merged launch."""
+    clips = np.random.default_rng(31).uniform(-1, 1, (2, 8, 128, 128, 3)).astype(np.float32)
+    for layout, nact, rep in (('pa16j2d', 15, True), ('pa17j3d', 60, False)):
+        monkeypatch.setenv('DEEPHAR_MERGE_KXK', '0')
+        base, _, _, _ = _spnet(8, layout, nact, 2, [1, 2], 160, replica=rep, res=128)
+        want = base.predict(clips, batch_size=2)
+        nbase = len(base.plan.steps)
+        monkeypatch.setenv('DEEPHAR_MERGE_KXK', '1')
+        m, _, _, _ = _spnet(8, layout, nact, 2, [1, 2], 160, replica=rep, res=128)
+        merged = [s for s in m.plan.steps if s.kind == 'conv' and (s.name or '').count('p_conv0') == 3]
+        assert len(merged) == 6 and len(m.plan.steps) == nbase - 12
+        assert all((s.attrs['kh'], s.attrs['kw'], s.attrs['Cout']) == (3, 5, 70) for s in merged)
+        for a, b in zip(want, m.predict(clips, batch_size=2)):
+            assert np.array_equal(a, b)
+        layer = next(l for n in m._nodes for l in n.layers.values() if l.name.endswith('act1_action_p_conv0a'))
+        layer.params[0].set(0.5 * layer.params[0].value)
+        next(l for n in base._nodes for l in n.layers.values() if l.name == layer.name).params[0].set(layer.params[0].value)
+        for a, b in zip(base.predict(clips, batch_size=2), m.predict(clips, batch_size=2)):
+            assert np.array_equal(a, b)
+
+
+def test_grouped_launches_are_bit_identical(hip_lib, cuda, monkeypatch):
+    """[r06] BoundPlan.group_launches: at a couple of clips per call every (1x1 shortcut convolution, depthwise convolution)
+    pair of SPNet's down- / up-scaling units is ONE launch (dh_conv2d_dw_group_f32) -- 2-D replica model, one and two
+    streams: the same bits as with the switch off, and the planned pairs are really merged; at a throughput batch nothing
+    is merged."""
+    clips = np.random.default_rng(29).uniform(-1, 1, (2, 8, 128, 128, 3)).astype(np.float32)
+    monkeypatch.setenv('DEEPHAR_GROUP_LAUNCHES', '0')
+    base, _, _, _ = _spnet(8, 'pa16j2d', 15, 2, [1, 2], 160, replica=True, res=128)
+    want = base.predict(clips, batch_size=2)
+    assert next(iter(base.executor.bound.values())).grouped == 0
+    monkeypatch.setenv('DEEPHAR_GROUP_LAUNCHES', '1')
+    for streams, policy in ((1, 'list'), (2, 'tail')):
+        m, _, _, _ = _spnet(8, 'pa16j2d', 15, 2, [1, 2], 160, replica=True, res=128)
+        m.num_streams, m.stream_policy = streams, policy
+        got = m.predict(clips, batch_size=2)
+        bp = next(iter(m.executor.bound.values()))
+        units = sum(1 for s in m.plan.steps if s.kind == 'conv' and (s.name or '').endswith('_r0_shortcut_conv'))
+        # 3 down- + 3 up-scaling units; at 128 px three of them have their depthwise half on maps of >= 8 columns (the LDS
+        # kernel the group is built from), the others run as two launches
+        assert units == 6 and bp.grouped == 3, (units, bp.grouped)
+        for a, b in zip(want, got):
+            assert np.array_equal(a, b), (streams, policy)
+    big = np.random.default_rng(30).uniform(-1, 1, (24, 8, 128, 128, 3)).astype(np.float32)
+    m.predict(big, batch_size=24)
+    assert m.executor.bound[24].grouped < bp.grouped                        # beyond the latency regime the pairs stay apart
+    # the C-level plan of the grouped form: the same bits from a blob (one function id more, the no-op entries left out)
+    import tempfile
+    from deephar_amd.engine import serialize
+    blob = serialize.dump_plan(m, 2)
+    assert serialize.FUNCTIONS[-1] == 'dh_conv2d_dw_group_f32' and len(blob) > 0
 
 
 def test_speed_protocol_truncated_models(hip_lib, cuda):

@@ -274,6 +274,68 @@ def test_dwconv_reads_an_upsampled_input(shape, k, hip_lib, cuda):
            O.depthwise_conv2d(O.relu(t(up) * t(ps) + t(pb)), t(dw)), atol=1e-5, what='dw of an up-sampled input')
 
 
+@pytest.mark.parametrize('case', [
+    # (frames, H, W, C, Cout, epilogue of the conv, depthwise reads the half-resolution x)
+    (16, 8, 8, 384, 480, 'plain', False),          # SPNet down-scaling unit on the 8 x 8 level (64-thread depthwise kernel)
+    (16, 16, 16, 288, 384, 'plain', False),        # ... 16 x 16 (256-thread depthwise kernel)
+    (16, 4, 4, 576, 480, 'plain', True),           # up-scaling unit: shortcut at 4 x 4, depthwise at 8 x 8 reading it up-sampled
+    (16, 16, 16, 384, 288, 'plain', True),         # ... depthwise at 32 x 32: several bands
+    (3, 8, 8, 96, 288, 'bn+res1', False),          # an epilogue on the conv side, ragged GEMM tiles (M = 192)
+    (2, 16, 16, 64, 272, 'res1+res2', False),
+])
+def test_conv_dw_grouped_launch(case, hip_lib, cuda):
+    """[r06] dh_conv2d_dw_group_f32: the 1x1 shortcut convolution and the depthwise convolution of a pre-activation residual
+    unit (common.py:25-67) as ONE launch -- bit for bit the two stand-alone launches (every work-group runs its kernel's own
+    code), incl. the up-scaling unit of planner rule R11 (conv at half resolution, depthwise up-samples on load)."""
+    import ctypes as C
+    from deephar_amd import functional as F, _lib
+    from deephar_amd.layers import same_pad
+    n, h, w, c, cout, epi, up = case
+    rng = np.random.default_rng(sum(int(v) for v in case[:5]) + len(epi))
+    x = _rand(rng, (n, h, w, c))
+    k = _rand(rng, (1, 1, c, cout), np.sqrt(1.0 / c))
+    dwk = _rand(rng, (5, 5, c, 1), 0.2)
+    ps, pb = rng.uniform(0.5, 1.5, c).astype(np.float32), _rand(rng, (c,), 0.3)
+    qs, qb = (rng.uniform(0.5, 1.5, cout).astype(np.float32), _rand(rng, (cout,), 0.3)) if 'bn' in epi else (None, None)
+    r1 = _rand(rng, (n, h, w, cout)) if 'res1' in epi else None
+    r2 = _rand(rng, (n, h, w, cout)) if 'res2' in epi else None
+    d = lambda a: None if a is None else torch.from_numpy(a).to(cuda)
+    xd, psd, pbd = d(x), d(ps), d(pb)
+    kw = dict(pre_scale=psd, pre_shift=pbd, pre_relu=True, post_scale=d(qs), post_shift=d(qb), res1=d(r1), res2=d(r2))
+    want_conv = F.conv2d(xd, k, **kw)
+    want_dw = F.dwconv2d(xd, dwk, pre_scale=psd, pre_shift=pbd, pre_relu=True, up_in=up)
+    torch.cuda.synchronize()
+    # the same two argument structs through the grouped entry point
+    wt, kp, np_ = F.pack_conv_weight(k, cuda)
+    dwt = torch.from_numpy(np.ascontiguousarray(dwk.reshape(25, c))).to(cuda)
+    yc = torch.full_like(want_conv, float('nan'))
+    yd = torch.full_like(want_dw, float('nan'))
+    keep = [d(qs), d(qb), d(r1), d(r2)]
+    ptr = lambda t_: t_.data_ptr() if t_ is not None else None
+    a = _lib.ConvArgs()
+    a.x, a.w, a.y, a.pre_scale, a.pre_shift = xd.data_ptr(), wt.data_ptr(), yc.data_ptr(), psd.data_ptr(), pbd.data_ptr()
+    a.post_scale, a.post_shift, a.res1, a.res2 = ptr(keep[0]), ptr(keep[1]), ptr(keep[2]), ptr(keep[3])
+    a.N, a.H, a.W, a.Cin, a.ldx, a.OH, a.OW, a.Cout, a.ldy = n, h, w, c, c, h, w, cout, cout
+    a.KH = a.KW = a.SH = a.SW = 1
+    a.K, a.Kp, a.Np, a.ldr1, a.ldr2, a.pre_relu = c, kp, np_, cout, cout, 1
+    g = _lib.DwArgs()
+    dh, dw_ = (2 * h, 2 * w) if up else (h, w)
+    g.x, g.w, g.y, g.pre_scale, g.pre_shift = xd.data_ptr(), dwt.data_ptr(), yd.data_ptr(), psd.data_ptr(), pbd.data_ptr()
+    g.N, g.H, g.W, g.C, g.ldx, g.ldy = n, dh, dw_, c, c, c
+    g.KH = g.KW = 5
+    g.PT, g.PL, g.pre_relu, g.up_in = same_pad(dh, 5, 1)[0], same_pad(dw_, 5, 1)[0], 1, int(up)
+    _lib.check(hip_lib.dh_conv2d_dw_group_f32(C.byref(a), C.byref(g), torch.cuda.current_stream().cuda_stream), 'group')
+    torch.cuda.synchronize()
+    assert torch.equal(yc, want_conv), 'conv half of the grouped launch differs'
+    assert torch.equal(yd, want_dw), 'depthwise half of the grouped launch differs'
+    # a pair the group does not cover answers DH_EUNSUPPORTED and touches nothing
+    a.pre_relu = 0
+    yc.fill_(7.0)
+    assert hip_lib.dh_conv2d_dw_group_f32(C.byref(a), C.byref(g), torch.cuda.current_stream().cuda_stream) == -2
+    torch.cuda.synchronize()
+    assert bool((yc == 7.0).all())
+
+
 @pytest.mark.parametrize('h,w,c,k', [(32, 32, 64, 5), (16, 16, 32, 5), (8, 8, 32, 3), (40, 64, 32, 3)])
 def test_dwconv_on_channel_slabs(h, w, c, k, hip_lib, cuda):
     """The planner hands the depthwise kernel views into wider tensors (concat slabs): ldx, ldy > C and a channel offset.

@@ -23,11 +23,14 @@ def _plan(lib, blob):
     return h
 
 
-@pytest.mark.parametrize('kind', ['reception2d', 'reception3d', 'merge'])
+@pytest.mark.parametrize('kind', ['reception2d', 'reception3d', 'merge', 'spnet'])
 def test_c_plan_reproduces_predict_bit_for_bit(kind, hip_lib, cuda, tmp_path):
-    from test_gpu_models import _build, _merge
+    from test_gpu_models import _build, _merge, _spnet
     rng = np.random.default_rng(17)
-    if kind == 'reception2d':
+    if kind == 'spnet':          # [r06] planner rule R11 (dh_dw_args.up_in) and the grouped launches (dh_conv2d_dw_group_f32) in a blob
+        m, _, _, _ = _spnet(8, 'pa16j2d', 15, 2, [1, 2], 160, replica=True, res=128)
+        x = rng.uniform(-1, 1, (3, 8, 128, 128, 3)).astype(np.float32)
+    elif kind == 'reception2d':
         m, _ = _build(2, 2, 16, num_context_per_joint=2, concat_pose_confidence=False)
         x = rng.uniform(-1, 1, (5, 256, 256, 3)).astype(np.float32)
     elif kind == 'reception3d':
@@ -39,6 +42,9 @@ def test_c_plan_reproduces_predict_bit_for_bit(kind, hip_lib, cuda, tmp_path):
     n = len(x)
     ref = m.predict(x, batch_size=n)
     ref = ref if isinstance(ref, list) else [ref]
+    if kind == 'spnet':
+        bp = m.executor.bound[n]
+        assert bp.grouped == 3 and sum(1 for s_ in m.plan.steps if s_.kind == 'dwconv' and s_.attrs.get('up_in')) == 3
     path = str(tmp_path / 'model.dhplan')
     nbytes = m.export_plan(path, n)
     blob = open(path, 'rb').read()
