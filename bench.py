@@ -268,7 +268,7 @@ def epilogue_tag(s):
     parts = []
     if a.get('pre_relu'):
         parts.append('prerelu')
-    if 'post_bn' in s.params:
+    if 'post_bn' in s.params or 'post_affine' in s.params:
         parts.append('bn')
     if s.ins.get('res1') is not None:
         parts.append('res1')

@@ -71,16 +71,27 @@ class WeightStore:
             self.dw[id(p)] = ent
         return ent[0]
 
+    def _bn_host(self, layer):
+        byrole = {p.role: self._require(p) for p in layer.params}
+        inv = (np.float32(1.0) / np.sqrt(byrole['var'].astype(np.float32) + np.float32(BN_EPS))).astype(np.float32)
+        if 'gamma' in byrole:
+            inv = (inv * byrole['gamma']).astype(np.float32)
+        return inv, (byrole['beta'] - byrole['mean'] * inv).astype(np.float32)
+
     def bn_affine(self, layer):
-        """BatchNormalization inference as y = x*scale + shift (fp32, like tf.nn.batch_normalization)."""
+        """BatchNormalization inference as y = x*scale + shift (fp32, like tf.nn.batch_normalization).  A
+        planner.ConcatAffine (the affine behind a horizontally merged convolution, rule R10c) gives the per-column scale /
+        shift of its parts side by side, identity (1, 0) for a part without a BatchNormalization."""
         vers = tuple(p.version for p in layer.params)
         ent = self.bn.get(id(layer))
         if ent is None or ent[2] != vers:
-            byrole = {p.role: self._require(p) for p in layer.params}
-            inv = (np.float32(1.0) / np.sqrt(byrole['var'].astype(np.float32) + np.float32(BN_EPS))).astype(np.float32)
-            if 'gamma' in byrole:
-                inv = (inv * byrole['gamma']).astype(np.float32)
-            shift = (byrole['beta'] - byrole['mean'] * inv).astype(np.float32)
+            if hasattr(layer, 'parts'):
+                pieces = [self._bn_host(l) if l is not None else (np.ones(c, np.float32), np.zeros(c, np.float32))
+                          for c, l in layer.parts]
+                inv = np.concatenate([a for a, _ in pieces]).astype(np.float32)
+                shift = np.concatenate([b for _, b in pieces]).astype(np.float32)
+            else:
+                inv, shift = self._bn_host(layer)
             if ent is None:
                 ent = (self._dev(inv), self._dev(shift), vers)
             else:
@@ -231,8 +242,8 @@ class BoundPlan:
             if 'pre_bn' in s.params:
                 sc, sh = self.store.bn_affine(s.params['pre_bn'])
                 args.pre_scale, args.pre_shift = sc.data_ptr(), sh.data_ptr()
-            if 'post_bn' in s.params:
-                sc, sh = self.store.bn_affine(s.params['post_bn'])
+            if 'post_bn' in s.params or 'post_affine' in s.params:
+                sc, sh = self.store.bn_affine(s.params.get('post_bn') or s.params['post_affine'])
                 args.post_scale, args.post_shift = sc.data_ptr(), sh.data_ptr()
             up = 2 if a['up2'] else 1
             args.N = n * x.lead(3)
@@ -544,7 +555,7 @@ class BoundPlan:
                  r1.ld % 4 if r1 is not None else 0, r2.ld % 4 if r2 is not None else 0)
         return (x.lead(3), x.shape[-3], x.shape[-2], x.C, x.ld, y.ld, a['Cout'], a['kh'], a['kw'], a['sh'],
                 a['sw'], a['pre_relu'], a['post_relu'], a['up2'], 'res1' in step.ins, 'res2' in step.ins,
-                'pre_bn' in step.params, 'post_bn' in step.params, a['pt'], a['pl'], y.shape[-3], y.shape[-2], a.get('res2_down', 0), 'ypool' in step.outs) + align
+                'pre_bn' in step.params, 'post_bn' in step.params or 'post_affine' in step.params, a['pt'], a['pl'], y.shape[-3], y.shape[-2], a.get('res2_down', 0), 'ypool' in step.outs) + align
 
     def autotune(self, stream_ptr, table=None, reps=3):
         """Time every tile configuration of dh_conv2d_f32 for each distinct conv shape of this bound plan

@@ -118,6 +118,19 @@ class ConcatParam:
         return sum(p.version for p in self.parts)
 
 
+class ConcatAffine:
+    """The BatchNormalization behind a horizontally merged convolution whose parts disagree about it (rule R10c): per part
+    its BatchNormalization layer, or None for a part without one (scale 1, shift 0: `t * 1 + 0` is t).  The executor's
+    weight store assembles the per-column scale / shift (WeightStore.affine_concat)."""
+
+    def __init__(self, parts):
+        self.parts = list(parts)          # [(channels, graph.Layer or None)]
+
+    @property
+    def params(self):
+        return [p for _, layer in self.parts if layer is not None for p in layer.params]
+
+
 class Step:
     def __init__(self, kind, ins, outs, attrs=None, params=None, name=None):
         self.stream, self.deps, self.wait, self.record = 0, [], [], False   # filled by schedule.finalize
@@ -420,6 +433,7 @@ class Planner:
             v.buf.pinned = True
             self.plan.outputs.append(v)
         self._merge_sibling_pointwise()
+        self._merge_siblings_into_joint_buffers()
         self._collect_params()
         from . import schedule
         schedule.finalize(self.plan, self.nstreams, self.stream_policy)
@@ -499,6 +513,114 @@ class Planner:
             if (wcat.kh, wcat.kw) == (1, 1):
                 attrs.update(pt=first.attrs['pt'], pl=first.attrs['pl'])
             merged = Step('conv', dict(first.ins), dict(y=y), attrs, params, '%s+%s' % (first.name, second.name))
+            del steps[j]
+            steps[i] = merged
+            for v in (ya, yb, y):
+                self.producer[id(v)] = merged
+
+    # ---- R10c: sibling 1x1 convolutions with outputs of their own become one launch into a joint buffer ----------------
+    def _merge_siblings_into_joint_buffers(self):
+        """[r06] Two plain 1x1 convolutions of the SAME tensor under the SAME prologue whose results are separate tensors --
+        the shortcut and the first convolution of a 'normal' residual unit (common.py:33-52: `shortcut = conv2d(relu(BN(x)))`
+        beside `conv2d(relu(BN(x)), out / div)`), the replica heat-map head beside the forward / heat-map pair (spnet.py:
+        32-38) -- are ONE launch over both weight matrices into a joint buffer; every reader takes its channel run as a
+        (pointer, pitch) view.  The parts may disagree about what follows them: a BatchNormalization becomes a per-column
+        affine of the merged launch (identity columns for the part without one, ConcatAffine), and a ReLU that only one part
+        has moves into the prologue of that part's readers (convolutions reading it as their input: relu on load = relu on
+        store).  Same products, same chains: bit-identical.  Only inside one kernel family (the skinny-conv rule must say
+        the same for the parts and the whole: round 4 measured that the wide pairs of the entry flow tile worse together
+        than apart).  DEEPHAR_MERGE_SIBLINGS=0 switches it off."""
+        if os.environ.get('DEEPHAR_MERGE_SIBLINGS', '1') == '0':
+            return
+        steps = self.plan.steps
+
+        def plain(st):
+            return st.kind == 'conv' and set(st.ins) == {'x'} and set(st.outs) == {'y'} and \
+                (st.attrs['kh'], st.attrs['kw'], st.attrs.get('sh', 1), st.attrs.get('sw', 1)) == (1, 1, 1, 1) and \
+                not st.attrs['up2'] and not st.attrs['res2_down'] and not (set(st.params) - {'w', 'pre_bn', 'post_bn'})
+
+        def readers(buf):
+            return [(q, role, v) for q in steps for role, v in q.ins.items() if v is not None and v.buf is buf]
+
+        def family(st, c):
+            y = st.outs['y']
+            px = y.shape[-3] * y.shape[-2] if len(y.shape) >= 3 else 1
+            return split_k_rule(px, st.attrs['K'], c, st.attrs['Cin'])
+
+        def compatible(a, b):
+            if not plain(a) or not plain(b) or a.params.get('pre_bn') is not b.params.get('pre_bn') or \
+                    a.attrs['pre_relu'] != b.attrs['pre_relu'] or a.attrs['Cin'] != b.attrs['Cin']:
+                return False
+            xa, xb, ya, yb = a.ins['x'], b.ins['x'], a.outs['y'], b.outs['y']
+            if xa.buf is not xb.buf or (xa.coff, xa.ld, xa.shape) != (xb.coff, xb.ld, xb.shape):
+                return False
+            if ya.buf is yb.buf or ya.shape[:-1] != yb.shape[:-1] or ya.buf.pinned or yb.buf.pinned:
+                return False
+            for st in (a, b):                 # each part fills ITS buffer completely, and nobody else writes into it
+                y = st.outs['y']
+                if y.coff != 0 or y.ld != y.C or y.buf.items != (int(np.prod(y.shape)) + 3) // 4 * 4:
+                    return False
+                if any(v is not None and v.buf is y.buf for q in steps if q is not st for v in q.outs.values()):
+                    return False
+            # this pass is for the skinny-conv family (16-column tiles: any widths tile together as well as apart)
+            if not (family(a, ya.C) and family(b, yb.C) and family(a, ya.C + yb.C)):
+                return False
+            for st in (a, b):                 # readers must take (pointer, pitch) views
+                for q, role, v in readers(st.outs['y'].buf):
+                    if q.kind not in ('conv', 'sam'):
+                        return False
+            if a.attrs['post_relu'] != b.attrs['post_relu']:      # the ReLU of one part moves to that part's readers
+                st = a if a.attrs['post_relu'] else b
+                for q, role, v in readers(st.outs['y'].buf):
+                    if q.kind != 'conv' or role != 'x' or 'pre_bn' in q.params:
+                        return False
+            return True
+
+        # candidates share the input view and the prologue: only those are compared (a sibling may sit far down the list --
+        # the replica head is emitted with its action head -- and is pulled up to the first one's place: it reads nothing
+        # but x, which exists there)
+        def key(st):
+            x = st.ins['x']
+            return (id(x.buf), x.coff, x.ld, x.shape, id(st.params.get('pre_bn')), st.attrs['pre_relu'])
+
+        i = 0
+        while i + 1 < len(steps):
+            a = steps[i]
+            j = None
+            if plain(a):
+                ka = key(a)
+                j = next((j for j in range(i + 1, len(steps)) if plain(steps[j]) and key(steps[j]) == ka and
+                          compatible(a, steps[j])), None)
+            if j is None:
+                i += 1
+                continue
+            b = steps[j]
+            ya, yb = a.outs['y'], b.outs['y']
+            ca, cb = ya.C, yb.C
+            post_relu = int(a.attrs['post_relu'] and b.attrs['post_relu'])
+            if a.attrs['post_relu'] != b.attrs['post_relu']:
+                st = a if a.attrs['post_relu'] else b
+                for q, role, v in readers(st.outs['y'].buf):
+                    q.attrs['pre_relu'] = 1
+            joint = self.new_buf(ya.shape[:-1] + (ca + cb,))
+            for old, base in ((ya.buf, 0), (yb.buf, ca)):
+                for q in steps:
+                    for v in list(q.ins.values()) + list(q.outs.values()):
+                        if v is not None and v.buf is old:
+                            v.buf, v.coff, v.ld = joint, v.coff + base, ca + cb
+                self.plan.bufs.remove(old)
+            parts = []
+            for st in (a, b):
+                w = st.params['w']
+                parts += w.parts if isinstance(w, ConcatParam) else [w]
+            params = dict(w=ConcatParam(parts))
+            if 'pre_bn' in a.params:
+                params['pre_bn'] = a.params['pre_bn']
+            if 'post_bn' in a.params or 'post_bn' in b.params:
+                params['post_affine'] = ConcatAffine([(ca, a.params.get('post_bn')), (cb, b.params.get('post_bn'))])
+            y = Value(ya.shape[:-1] + (ca + cb,), joint, 0, ca + cb)
+            merged = Step('conv', dict(a.ins), dict(y=y), dict(a.attrs, Cout=ca + cb, post_relu=post_relu), params,
+                          '%s+%s' % (a.name, b.name))
             del steps[j]
             steps[i] = merged
             for v in (ya, yb, y):

@@ -166,6 +166,7 @@ def test_heat_map_head_rules_are_bit_identical(hip_lib, cuda, monkeypatch):
     neighbouring slabs, as ONE launch over both weight matrices): fewer launches, not one bit moved -- 2-D and 3-D SPNet,
     with and without the replica head; weights changed after the first predict reach the merged launch."""
     from deephar_amd import weights
+    monkeypatch.setenv('DEEPHAR_MERGE_SIBLINGS', '0')      # (rule R10c has its own test; here: R4b and R10 alone)
     for layout, nact, rep in (('pa16j2d', 15, True), ('pa17j3d', 60, False)):
         clips = np.random.default_rng(21).uniform(-1, 1, (2, 4, 128, 128, 3)).astype(np.float32)
         monkeypatch.setenv('DEEPHAR_MERGE_HEADS', '0')
@@ -210,6 +211,41 @@ def test_merged_kxk_siblings_are_bit_identical(hip_lib, cuda, monkeypatch):
         layer = next(l for n in m._nodes for l in n.layers.values() if l.name.endswith('act1_action_p_conv0a'))
         layer.params[0].set(0.5 * layer.params[0].value)
         next(l for n in base._nodes for l in n.layers.values() if l.name == layer.name).params[0].set(layer.params[0].value)
+        for a, b in zip(base.predict(clips, batch_size=2), m.predict(clips, batch_size=2)):
+            assert np.array_equal(a, b)
+
+
+def test_siblings_merged_into_joint_buffers_are_bit_identical(hip_lib, cuda, monkeypatch):
+    """[r06] Planner rule R10c: sibling 1x1 convolutions of one tensor whose results are separate tensors -- shortcut and
+    first convolution of the action heads' 'normal' residual units (common.py:33-52), the replica heat-map head beside the
+    forward / heat-map pair (spnet.py:32-38) -- as ONE launch into a joint buffer, with a per-column affine where only one
+    part has a BatchNormalization and the odd ReLU moved into its reader's prologue: fewer launches, not one bit moved;
+    2-D replica model and 3-D model, one and two streams; weights set after the first predict reach the merged launch."""
+    from deephar_amd.engine.planner import ConcatAffine
+    clips = np.random.default_rng(33).uniform(-1, 1, (2, 8, 128, 128, 3)).astype(np.float32)
+    for layout, nact, rep in (('pa16j2d', 15, True), ('pa17j3d', 60, False)):
+        monkeypatch.setenv('DEEPHAR_MERGE_SIBLINGS', '0')
+        base, _, _, _ = _spnet(8, layout, nact, 2, [1, 2], 160, replica=rep, res=128)
+        want = base.predict(clips, batch_size=2)
+        nbase = len(base.plan.steps)
+        monkeypatch.setenv('DEEPHAR_MERGE_SIBLINGS', '1')
+        for streams, policy in ((1, 'list'), (2, 'tail')):
+            m, _, _, _ = _spnet(8, layout, nact, 2, [1, 2], 160, replica=rep, res=128)
+            m.num_streams, m.stream_policy = streams, policy
+            res_units = [s for s in m.plan.steps if isinstance(s.params.get('post_affine'), ConcatAffine)]
+            heads3 = [s for s in m.plan.steps if s.kind == 'conv' and 'replica' in (s.name or '') and '+' in s.name]
+            assert len(res_units) == 12 and len(heads3) == (6 if rep else 0)       # six action heads x (r1, r2); six replica heads
+            assert len(m.plan.steps) == nbase - 12 - len(heads3)
+            for a, b in zip(want, m.predict(clips, batch_size=2)):
+                assert np.array_equal(a, b), (layout, streams)
+        layer = next(l for n in m._nodes for l in n.layers.values() if l.name.endswith('act1_action_r1_conv1'))
+        layer.params[0].set(0.5 * layer.params[0].value)
+        next(l for n in base._nodes for l in n.layers.values() if l.name == layer.name).params[0].set(layer.params[0].value)
+        bn = next(l for n in m._nodes for l in n.layers.values() if l.name.endswith('act1_action_r1_bn2'))
+        new_beta = bn.params[[p.role for p in bn.params].index('beta')]
+        new_beta.set(new_beta.value + 0.25)
+        bb = next(l for n in base._nodes for l in n.layers.values() if l.name == bn.name)
+        bb.params[[p.role for p in bb.params].index('beta')].set(new_beta.value)
         for a, b in zip(base.predict(clips, batch_size=2), m.predict(clips, batch_size=2)):
             assert np.array_equal(a, b)
 
