@@ -18,7 +18,7 @@ class ConvArgs(C.Structure):
                                    'res1', 'res2', 'in_lut')] + \
                [(n, i32) for n in ('N', 'H', 'W', 'Cin', 'ldx', 'OH', 'OW', 'Cout', 'ldy', 'KH', 'KW', 'SH',
                                    'SW', 'PT', 'PL', 'K', 'Kp', 'Np', 'ldr1', 'ldr2', 'pre_relu', 'post_relu',
-                                   'up2', 'x_u8', 'w_split', 'res2_down', 'ldyp')] + [('y_pool', vp)]
+                                   'up2', 'x_u8', 'w_split', 'res2_down', 'ldyp', 'x_resample')] + [('y_pool', vp)]
 
 
 class DwArgs(C.Structure):

@@ -1,5 +1,6 @@
 // extern "C" surface of libdeephar_hip.so (see include/deephar_hip.h for the contract and the
 // reference interfaces each entry point replaces).  Thin: validate, forward to the launcher.
+#include <stddef.h>
 #include <string.h>
 #include <vector>
 #include "dh_kernels.h"
@@ -7,6 +8,11 @@
 using namespace dh;
 
 static inline hipStream_t S(void* s) { return reinterpret_cast<hipStream_t>(s); }
+// the fields added in round 6 (dh_conv_args.x_resample, dh_dw_args.up_in) sit in what was padding: serialised plans and
+// foreign callers built against the older header keep their layout
+static_assert(sizeof(dh_conv_args) == 200 && offsetof(dh_conv_args, y_pool) == 192 && offsetof(dh_conv_args, x_resample) == 188,
+              "dh_conv_args layout");
+static_assert(sizeof(dh_dw_args) == 88 && offsetof(dh_dw_args, up_in) == 84, "dh_dw_args layout");
 static inline int rc_of(hipError_t e) { return e == hipSuccess ? DH_OK : DH_ELAUNCH; }
 
 extern "C" {

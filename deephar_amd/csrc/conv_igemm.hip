@@ -319,6 +319,7 @@ int launch_conv_igemm(const ConvArgs& a, int cfg, hipStream_t s) {
                     (reinterpret_cast<uintptr_t>(a.y) & 15) == 0 && !conv_is_skinny(a);
     if (!ok) return DH_EUNSUPPORTED;
   }
+  if (a.x_resample && !conv_is_skinny(a)) return DH_EUNSUPPORTED;   // (resampling on load: the skinny-conv kernel only)
   if (conv_is_skinny(a)) {
     if (a.res2_down) return DH_EUNSUPPORTED;          // (the split-K kernel has its own, simpler epilogue)
     return cfg < kNumCfgs + gemm1x1_num_cfgs() ? launch_conv_splitk(a, s) : DH_EINVAL;

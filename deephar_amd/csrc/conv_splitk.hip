@@ -27,7 +27,11 @@ namespace {
 
 constexpr int SK_MAX_CIN = 4096; // prologue table in LDS: 2 x Cin floats
 
-template <int NWV, bool VEC>
+// RS = dh_conv_args.x_resample [r06]: 0 = x as it is; 1 = x is stored at HALF resolution and read as UpSampling2D((2, 2))(x)
+// (input pixel (h, w) = x(h / 2, w / 2)); 2 / 3 = x is stored at DOUBLE resolution and read through MaxPooling2D((2, 2)) /
+// layers.max_min_pooling((2, 2)) (max, or max + min, of the four pixels) -- the prologue and the zero padding act on the
+// resampled pixels, exactly as if the up-sampling / pooling launch had written them out.
+template <int NWV, bool VEC, int RS>
 __global__ __launch_bounds__(NWV * 64) void conv_skinny_kernel(const ConvArgs p, const unsigned magic_cin, const unsigned magic_kw) {
   extern __shared__ __attribute__((aligned(16))) float sk_lds[];
   float (*red)[4][64] = reinterpret_cast<float (*)[4][64]>(sk_lds);            // [NWV][4][64] partial tiles
@@ -41,7 +45,10 @@ __global__ __launch_bounds__(NWV * 64) void conv_skinny_kernel(const ConvArgs p,
   const int n0 = (blockIdx.x % tiles_n) * 16;
   const bool aff = p.pre_scale != nullptr;
   const int cin4 = (p.Cin + 3) & ~3;
-  constexpr int SK_DEPTH = VEC ? 8 : 4;                   // k-group quads in flight per wave (dword form: 4 loads per quad and lane)
+  constexpr int SK_DEPTH = RS >= 2 ? (VEC ? 4 : 2) : (VEC ? 8 : 4);   // k-group quads in flight per wave (dword form: 4 loads per quad and
+                                                          // lane; pooled input: four pixels per element)
+  // physical extent of x, and the pixel pitch between the four pixels of a pooled window
+  const int PH = RS == 1 ? p.H >> 1 : (RS >= 2 ? p.H << 1 : p.H), PW = RS == 1 ? p.W >> 1 : (RS >= 2 ? p.W << 1 : p.W);
 
   // this lane's output pixel (A operand row) and its top-left input position
   int m = m0 + li;
@@ -50,7 +57,7 @@ __global__ __launch_bounds__(NWV * 64) void conv_skinny_kernel(const ConvArgs p,
   const int rem = m - fr * (p.OH * p.OW);
   const int oh = rem / p.OW, ow = rem - oh * p.OW;
   const int ih0 = oh * p.SH - p.PT, iw0 = ow * p.SW - p.PL;
-  const float* xf = p.x + (size_t)fr * p.H * p.W * p.ldx;
+  const float* xf = p.x + (size_t)fr * PH * PW * p.ldx;
   const int ncol = n0 + li < p.Np ? n0 + li : p.Np - 1;   // (Np is a multiple of 32: always in range; belt and braces)
   const float* wcol = p.w + (size_t)ncol * 4;             // packed [Kp / 4][Np][4]: unit (k-group, column)
   const int quads = p.Kp / 16;                            // 16 k each: lane group lg takes k-group 4 q + lg
@@ -68,7 +75,15 @@ __global__ __launch_bounds__(NWV * 64) void conv_skinny_kernel(const ConvArgs p,
     const int kw = tap - kh * p.KW;
     const int ih = ih0 + kh, iw = iw0 + kw;
     const bool ok = k < p.K && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
+    if constexpr (RS == 1) return ok ? ((ih >> 1) * PW + (iw >> 1)) * p.ldx + c : -1;
+    if constexpr (RS >= 2) return ok ? (2 * ih * PW + 2 * iw) * p.ldx + c : -1;          // top-left pixel of the 2 x 2 window
     return ok ? (ih * p.W + iw) * p.ldx + c : -1;
+  };
+  // one input element (or float4 of them) through the pooling window
+  auto pool4 = [&](float a, float b, float c_, float d) -> float {
+    const float mx = fmaxf(fmaxf(a, b), fmaxf(c_, d));
+    if constexpr (RS == 3) return mx + fminf(fminf(a, b), fminf(c_, d));
+    return mx;
   };
 
   bool tab_ready = !aff;
@@ -87,7 +102,16 @@ __global__ __launch_bounds__(NWV * 64) void conv_skinny_kernel(const ConvArgs p,
         int c;
         const int off = locate(k0, c);
         const bool ok = live && off >= 0;
-        fa[d] = *reinterpret_cast<const float4*>(xf + (ok ? off : 0));
+        if constexpr (RS >= 2) {
+          const float* q0 = xf + (ok ? off : 0);
+          const float4 v00 = *reinterpret_cast<const float4*>(q0), v01 = *reinterpret_cast<const float4*>(q0 + p.ldx);
+          const float4 v10 = *reinterpret_cast<const float4*>(q0 + (size_t)PW * p.ldx);
+          const float4 v11 = *reinterpret_cast<const float4*>(q0 + (size_t)(PW + 1) * p.ldx);
+          fa[d] = make_float4(pool4(v00.x, v01.x, v10.x, v11.x), pool4(v00.y, v01.y, v10.y, v11.y),
+                              pool4(v00.z, v01.z, v10.z, v11.z), pool4(v00.w, v01.w, v10.w, v11.w));
+        } else {
+          fa[d] = *reinterpret_cast<const float4*>(xf + (ok ? off : 0));
+        }
         ch[d] = c;
         okm |= (ok ? 1u : 0u) << d;
       } else {
@@ -97,7 +121,12 @@ __global__ __launch_bounds__(NWV * 64) void conv_skinny_kernel(const ConvArgs p,
           int c;
           const int off = locate(k0 + j, c);
           const bool ok = live && off >= 0;
-          e[j] = xf[ok ? off : 0];
+          if constexpr (RS >= 2) {
+            const float* q0 = xf + (ok ? off : 0);
+            e[j] = pool4(q0[0], q0[p.ldx], q0[(size_t)PW * p.ldx], q0[(size_t)(PW + 1) * p.ldx]);
+          } else {
+            e[j] = xf[ok ? off : 0];
+          }
           okm |= (ok ? 1u : 0u) << (4 * d + j);
         }
         fa[d] = make_float4(e[0], e[1], e[2], e[3]);
@@ -189,22 +218,33 @@ __global__ __launch_bounds__(NWV * 64) void conv_skinny_kernel(const ConvArgs p,
   }
 }
 
-template <int NWV>
-int launch_skinny(const ConvArgs& a, unsigned tiles, bool vec, hipStream_t s) {
+template <int NWV, int RS>
+int launch_skinny_rs(const ConvArgs& a, unsigned tiles, bool vec, hipStream_t s) {
   const unsigned magic_cin = (unsigned)((1ull << 32) / (unsigned)a.Cin + 1ull);       // k / Cin = umulhi(k, magic), k * Cin < 2^32
   const unsigned magic_kw = (1u << 16) / (unsigned)a.KW + 1u;                          // tap / KW for tap, KW < 2^8 (conv_is_skinny)
   const size_t lds = ((size_t)NWV * 4 * 64 + (a.pre_scale != nullptr ? (size_t)2 * ((a.Cin + 3) & ~3) : 0)) * sizeof(float);
   constexpr int lds_max = (NWV * 4 * 64 + 2 * SK_MAX_CIN) * (int)sizeof(float);      // <= 48 KB
   if (vec) {
     static LdsLimit lim;
-    if (lds_max > 64 * 1024) lim.raise((const void*)conv_skinny_kernel<NWV, true>, lds_max);
-    hipLaunchKernelGGL((conv_skinny_kernel<NWV, true>), dim3(tiles), dim3(NWV * 64), lds, s, a, magic_cin, magic_kw);
+    if (lds_max > 64 * 1024) lim.raise((const void*)conv_skinny_kernel<NWV, true, RS>, lds_max);
+    hipLaunchKernelGGL((conv_skinny_kernel<NWV, true, RS>), dim3(tiles), dim3(NWV * 64), lds, s, a, magic_cin, magic_kw);
   } else {
     static LdsLimit lim;
-    if (lds_max > 64 * 1024) lim.raise((const void*)conv_skinny_kernel<NWV, false>, lds_max);
-    hipLaunchKernelGGL((conv_skinny_kernel<NWV, false>), dim3(tiles), dim3(NWV * 64), lds, s, a, magic_cin, magic_kw);
+    if (lds_max > 64 * 1024) lim.raise((const void*)conv_skinny_kernel<NWV, false, RS>, lds_max);
+    hipLaunchKernelGGL((conv_skinny_kernel<NWV, false, RS>), dim3(tiles), dim3(NWV * 64), lds, s, a, magic_cin, magic_kw);
   }
   return check_launch();
+}
+
+template <int NWV>
+int launch_skinny(const ConvArgs& a, unsigned tiles, bool vec, hipStream_t s) {
+  switch (a.x_resample) {
+    case 0: return launch_skinny_rs<NWV, 0>(a, tiles, vec, s);
+    case 1: return launch_skinny_rs<NWV, 1>(a, tiles, vec, s);
+    case 2: return launch_skinny_rs<NWV, 2>(a, tiles, vec, s);
+    case 3: return launch_skinny_rs<NWV, 3>(a, tiles, vec, s);
+  }
+  return DH_EINVAL;
 }
 
 }  // namespace
@@ -230,7 +270,10 @@ int conv_skinny_waves(int Kp) {
 int launch_conv_splitk(const ConvArgs& a, hipStream_t s) {
   const long long M = (long long)a.N * a.OH * a.OW;
   const long long tiles = ((M + 15) / 16) * ((a.Cout + 15) / 16);
-  if (tiles <= 0 || tiles > 0x7fffffffLL || (long long)a.H * a.W * a.ldx > 0x7fffffffLL || a.Kp % 16 != 0) return DH_EINVAL;
+  if (tiles <= 0 || tiles > 0x7fffffffLL || (long long)a.H * a.W * a.ldx * (a.x_resample >= 2 ? 4 : 1) > 0x7fffffffLL ||
+      a.Kp % 16 != 0)
+    return DH_EINVAL;
+  if (a.x_resample < 0 || a.x_resample > 3 || (a.x_resample == 1 && ((a.H | a.W) & 1))) return DH_EINVAL;
   auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
   // (the vector form is a property of the layer wherever the engine lays tensors out 16-byte aligned; both forms load
   //  the same values and run the same arithmetic: same bits)

@@ -248,6 +248,10 @@ class BoundPlan:
             up = 2 if a['up2'] else 1
             args.N = n * x.lead(3)
             args.H, args.W, args.Cin, args.ldx = x.shape[-3], x.shape[-2], x.C, x.ld
+            rs = a.get('x_resample', 0)                # planner rule R12: x is stored at another resolution than the conv sees
+            if rs:
+                args.x_resample = rs
+                args.H, args.W = (2 * x.shape[-3], 2 * x.shape[-2]) if rs == 1 else (x.shape[-3] // 2, x.shape[-2] // 2)
             args.OH, args.OW, args.Cout, args.ldy = y.shape[-3] // up, y.shape[-2] // up, a['Cout'], y.ld
             args.KH, args.KW, args.SH, args.SW, args.PT, args.PL = a['kh'], a['kw'], a['sh'], a['sw'], a['pt'], a['pl']
             kp_np = (C.c_int(), C.c_int())

@@ -23,6 +23,9 @@ Fusion rules (what the reference leaves to TensorFlow as separate kernels):
                 residual slot (spnet.py:303) -- no element-wise launches are left for either.
   R5 decoder  : channel soft-max + both lin_interpolation_2d + joint confidence (+ global max) on the same
                 maps are one soft-argmax kernel (blocks.py:306-343).
+  R12 on load : [r06] a 2x2 / stride-2 (max or max+-min) pooling, or a nearest up-sampling, whose only reader is a convolution on
+                the skinny-conv kernel (the action heads: spnet.py:77-91) is not written out: that kernel resamples while it
+                loads its input (dh_conv_args.x_resample).  Bit-identical.
   R11 up-unit : [r06] UpSampling2D in FRONT of a residual unit (SPNet's up-scaling unit, common.py:89-108:
                 residual_unit(UpSampling2D(x)) -- BN, then a 1x1 shortcut convolution and a separable convolution, both of
                 relu(BN(.))) is never written out: nearest up-sampling commutes with everything element-wise and with a
@@ -200,6 +203,15 @@ class _UpView:
         self.low, self.shape, self.full = low, tuple(shape), None
 
 
+class _PoolView:
+    """A MaxPooling2D((2, 2)) / max_min_pooling((2, 2)) result that has not been written out (R12): `base` = the Value at full
+    resolution, `shape` = the pooled shape, `attrs` = the pooling node's attributes, `full` = the materialised Value once
+    some consumer needed one."""
+
+    def __init__(self, base, shape, attrs):
+        self.base, self.shape, self.attrs, self.full = base, tuple(shape), dict(attrs), None
+
+
 class Planner:
     def __init__(self, inputs, outputs, nstreams=1, stream_policy='list'):
         self.nstreams = nstreams
@@ -326,8 +338,12 @@ class Planner:
         v = self.val[t.uid]
         if isinstance(v, _UpView):                       # a consumer that needs the up-sampled tensor in memory
             v = self.val[t.uid] = self._realize_up(v)
+        if isinstance(v, _PoolView):
+            v = self.val[t.uid] = self._realize_pool(v)
         if isinstance(v, _Lazy) and isinstance(v.base, _UpView):
             v = _Lazy(self._realize_up(v.base), bn=v.bn, relu=v.relu)
+        if isinstance(v, _Lazy) and isinstance(v.base, _PoolView):
+            v = _Lazy(self._realize_pool(v.base), bn=v.bn, relu=v.relu)
         if isinstance(v, _Lazy):
             out = self.new_value(v.base.shape)
             self.emit('eltwise', dict(a=v.base), dict(y=out), dict(op=0, relu=int(v.relu)),
@@ -345,6 +361,32 @@ class Planner:
             uv.full = self.new_value(uv.shape)
             self.emit('upsample_add', dict(b=uv.low), dict(y=uv.full), name='upsample')
         return uv.full
+
+    def _realize_pool(self, pv):
+        """Write a virtual pooled tensor out after all (once): the stand-alone pooling launch."""
+        if pv.full is None:
+            pv.full = self.new_value(pv.shape)
+            self.emit('pool', dict(x=pv.base), dict(y=pv.full), dict(pv.attrs), name='pool')
+        return pv.full
+
+    def _skinny_conv_node(self, n, cin):
+        """True when conv node n (stride 1) runs on the skinny-conv kernel, which can resample its input on load (R12)."""
+        a, shape = n.attrs, n.outputs[0].shape
+        return n.op == 'conv' and len(shape) >= 3 and (a.get('sh', 1), a.get('sw', 1)) == (1, 1) and \
+            split_k_rule(shape[-3] * shape[-2], a['kh'] * a['kw'] * cin, a['filters'], cin, a['kh'], a['kw'])
+
+    def _only_reader_through_bn_relu(self, t):
+        """The single node that reads t through nothing but BatchNormalization / ReLU (each with one reader), or None."""
+        while True:
+            if self.out_uids.get(t.uid, 0):
+                return None
+            cs = self.consumers.get(t.uid, [])
+            if len(cs) != 1:
+                return None
+            n = cs[0][0]
+            if n.op not in ('bn', 'relu'):
+                return n
+            t = n.outputs[0]
 
     # ---- R11: UpSampling2D in front of a residual unit is not written out -----------------------------------------
     def _virtual_upsample_ok(self, node):
@@ -366,6 +408,8 @@ class Planner:
                         stack.append(n.outputs[0])
                 elif n.op == 'conv' and (n.attrs['kh'], n.attrs['kw'], n.attrs.get('sh', 1), n.attrs.get('sw', 1)) == (1, 1, 1, 1):
                     ends += 1
+                elif self._skinny_conv_node(n, t.shape[-1]) and os.environ.get('DEEPHAR_RESAMPLE_ON_LOAD', '1') != '0':
+                    ends += 1          # R12: the skinny-conv kernel up-samples on load (dh_conv_args.x_resample = 1)
                 elif n.op == 'sepconv' and (n.attrs.get('sh', 1), n.attrs.get('sw', 1)) == (1, 1):
                     ends += 1
                 else:
@@ -828,10 +872,21 @@ class Planner:
         self.val[t.uid] = _UpView(y, t.shape)
 
     def _emit_conv(self, x, pre_bn, pre_relu, param, a, out_t, name):
+        resample, cin = 0, x.shape[-1]
+        will_be_skinny = len(out_t.shape) >= 3 and (a.get('sh', 1), a.get('sw', 1)) == (1, 1) and \
+            split_k_rule(out_t.shape[-3] * out_t.shape[-2], a['kh'] * a['kw'] * cin, a['filters'], cin, a['kh'], a['kw'])
         if isinstance(x, _UpView):
             if x.full is None and (a['kh'], a['kw'], a.get('sh', 1), a.get('sw', 1)) == (1, 1, 1, 1) and len(out_t.shape) >= 3:
                 return self._emit_conv_before_upsampling(x, pre_bn, pre_relu, param, a, out_t, name)
-            x = self._realize_up(x)
+            if x.full is None and will_be_skinny and os.environ.get('DEEPHAR_RESAMPLE_ON_LOAD', '1') != '0':
+                x, resample = x.low, 1           # R12: the skinny-conv kernel reads the half-resolution tensor up-sampled
+            else:
+                x = self._realize_up(x)
+        elif isinstance(x, _PoolView):
+            if x.full is None and will_be_skinny:
+                x, resample = x.base, 2 + int(x.attrs.get('mode', 0))      # R12: ... or pools 2 x 2 windows on load
+            else:
+                x = self._realize_pool(x)
         skinny = len(out_t.shape) >= 3 and split_k_rule(out_t.shape[-3] * out_t.shape[-2], a['kh'] * a['kw'] * x.C,
                                                         a['filters'], x.C, a['kh'], a['kw'])
         epi, final_t = self._epilogue(out_t, skinny)
@@ -839,6 +894,8 @@ class Planner:
         attrs = dict(kh=a['kh'], kw=a['kw'], sh=a.get('sh', 1), sw=a.get('sw', 1), pt=a['pt'], pl=a['pl'],
                      Cin=x.C, Cout=a['filters'], K=a['kh'] * a['kw'] * x.C, pre_relu=int(pre_relu),
                      post_relu=int(epi['post_relu']), up2=int(epi['up2']), res2_down=int(epi['res2_down']))
+        if resample:
+            attrs['x_resample'] = resample
         ins = dict(x=x)
         if epi['res1'] is not None:
             ins['res1'] = epi['res1']
@@ -872,6 +929,8 @@ class Planner:
         if pre_bn is not None:
             params['pre_bn'] = pre_bn
         up_in = 0
+        if isinstance(x, _PoolView):
+            x = self._realize_pool(x)
         if isinstance(x, _UpView):               # R11: the depthwise half up-samples on load (dh_dw_args.up_in)
             if x.full is None and (a.get('sh', 1), a.get('sw', 1)) == (1, 1):
                 x, up_in = x.low, 1
@@ -954,13 +1013,24 @@ class Planner:
 
     def op_pool(self, node):
         x = self.materialize(node.inputs[0])
+        a = node.attrs
+        # R12 [r06]: a 2 x 2 / stride-2 pooling (max, or max +- min: layers.py:411-425) whose only reader -- through
+        # BatchNormalization / ReLU -- is a convolution on the skinny-conv kernel is not written out: that kernel takes the
+        # maximum (+ minimum) of the four pixels while it loads its input (dh_conv_args.x_resample = 2 / 3).  The action
+        # head's `conv2h` on max_min_pooling(x1) (spnet.py:77-84): one launch less per head.
+        if os.environ.get('DEEPHAR_RESAMPLE_ON_LOAD', '1') != '0' and len(x.shape) >= 3 and a.get('mode', 0) in (0, 1) and \
+                (a['kh'], a['kw'], a['sh'], a['sw'], a['pt'], a['pl']) == (2, 2, 2, 2, 0, 0) and x.shape[-3] % 2 == 0 and \
+                x.shape[-2] % 2 == 0:
+            reader = self._only_reader_through_bn_relu(node.outputs[0])
+            if reader is not None and self._skinny_conv_node(reader, x.C):
+                self.val[node.outputs[0].uid] = _PoolView(x, node.outputs[0].shape, a)
+                return
         y = self.out_value_for(node.outputs[0])
         # R7: MaxPooling2D((2, 2)) of a convolution's output at 32 columns is written by that convolution's epilogue as a
         # second output (dh_conv_args.y_pool) -- the stand-alone pool reads the whole tensor back from HBM
         # (reception.py:105-116: every hourglass level is used at full AND at half resolution).  Bit-identical.  Neutral
         # while the pool ran beside other work on a second stream (round 2); on ONE stream, where the forward is the sum
         # of its kernels, it is worth 1-2 % on the MPII model.  DEEPHAR_FUSE_POOL=0 switches it off.
-        a = node.attrs
         prod = self.producer.get(id(x))
         if os.environ.get('DEEPHAR_FUSE_POOL', '1') != '0' and prod is not None and prod.kind == 'conv' and \
                 prod.outs.get('y') is x and 'ypool' not in prod.outs and not prod.attrs.get('up2') and \

@@ -119,7 +119,7 @@ def assign_streams_tail(plan, deps, items=2, nstreams=2):
     heads' front ends, which then run ahead of the chain.
     s and x minimise the simulated makespan under a per-step cost of a launch floor plus the step's arithmetic / bytes
     for `items` batch items; no split is made when it would not save 5 % of the serial time.
-    `items` = 2 and the cost constants (7.5 us per launch, 90 TFLOP/s, 3 TB/s) are those of the regime the policy exists
+    `items` = 2 and the cost constants (30 us per launch [r06: see below], 90 TFLOP/s, 3 TB/s) are those of the regime the policy exists
     for -- two clips per call on an MI355X.  A Plan serves every batch size it is later bound to, so the split
     is NOT re-tuned per batch: any split is correct and bit-identical (the waits follow the data dependencies), a batch far
     from two clips merely runs a split balanced for two.  Throughput-regime callers keep the default (one stream).
@@ -129,9 +129,18 @@ def assign_streams_tail(plan, deps, items=2, nstreams=2):
     stream, order = [0] * n, list(range(n))
     if n < 8:
         return stream, order
-    # (calibrated on the speed2d forward, profiles/r05_steps_speed2d.json: ~7.5 us per small launch in a graph, the entry
-    #  flow's big convolutions at ~90 TFLOP/s)
-    cost = [7.5 + max(st.flops(items) / 90e12, st.bytes(items) / 3e12) * 1e6 for st in plan.steps]
+    # (round 5: ~7.5 us per small launch in a one-stream graph, the entry flow's big convolutions at ~90 TFLOP/s)
+    # [r06] re-calibrated against MEASURED two-stream step times: with the round-5 constant of 7.5 us per launch the split left
+    # the origin stream idle for the last 1.3 ms of a 5.3 ms forward (tools/r06/stream_timeline.py: the side stream's small
+    # launches cost 10-14 us each while another stream shares the chip, and it carries the last pose block behind every older
+    # action launch).  Sweep of this constant on the speed2d forward, same box: 7.5 -> 4.13 ms, 10.5 -> 4.05, 15 -> 4.00,
+    # 20 ... 40 -> 3.96 ... 3.99, 60 -> 4.03, 100 -> 4.05 (profiles/r06_tail_policy_calibration.txt): the split is mostly a
+    # balance of launch COUNTS.  (Also tried there: a critical-path-first order and a backbone-first order in front of the
+    # suffix search -- 4.8-5.2 ms and 4.2-4.3 ms: the suffix of the planner's own block-by-block order is the best of the
+    # three.)  DEEPHAR_TAIL_FLOOR_US overrides it for such sweeps.
+    import os
+    floor = float(os.environ.get('DEEPHAR_TAIL_FLOOR_US', '30'))
+    cost = [floor + max(st.flops(items) / 90e12, st.bytes(items) / 3e12) * 1e6 for st in plan.steps]
     consumers = [[] for _ in range(n)]
     for j, d in enumerate(deps):
         for i in d:

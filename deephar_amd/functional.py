@@ -45,7 +45,7 @@ def pack_conv_weight(w_hwio, device='cuda'):
 
 def conv2d(x, w_hwio, strides=(1, 1), padding='same', pre_scale=None, pre_shift=None, pre_relu=False,
            post_scale=None, post_shift=None, post_relu=False, res1=None, res2=None, up2=False, tile_cfg=-1,
-           packed=None, in_lut=None, split=False, halo=False, res2_down=False, pool2=False):
+           packed=None, in_lut=None, split=False, halo=False, res2_down=False, pool2=False, x_resample=0):
     """Fused conv (see dh_conv2d_f32).  x [N,H,W,Cin]; w_hwio numpy [kh,kw,Cin,Cout].  A uint8 `x` needs
     `in_lut` (float32 [Cin,256] device tensor, engine.executor.normalization_lut): bytes are normalised on load."""
     torch = _t()
@@ -61,6 +61,8 @@ def conv2d(x, w_hwio, strides=(1, 1), padding='same', pre_scale=None, pre_shift=
     kh, kw, cin, cout = w_hwio.shape
     n, h, w_, c = x.shape
     assert c == cin
+    if x_resample:             # dh_conv_args.x_resample: x is stored at half (1) / double (2, 3) the resolution the conv sees
+        h, w_ = (2 * h, 2 * w_) if x_resample == 1 else (h // 2, w_ // 2)
     if padding == 'same':
         pt, _, oh = same_pad(h, kh, strides[0])
         pl, _, ow = same_pad(w_, kw, strides[1])
@@ -89,6 +91,7 @@ def conv2d(x, w_hwio, strides=(1, 1), padding='same', pre_scale=None, pre_shift=
     a.ldr2 = res2.shape[-1] if res2 is not None else 0
     a.pre_relu, a.post_relu, a.up2 = int(pre_relu), int(post_relu), int(up2)
     a.res2_down = int(res2_down)
+    a.x_resample = int(x_resample)
     if x.dtype == torch.uint8:
         a.in_lut, a.x_u8 = _p(in_lut), 1
     yp = None

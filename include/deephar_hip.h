@@ -83,6 +83,15 @@ typedef struct dh_conv_args {
                         (reception.py:122-127: `b = UpSampling2D((2, 2))(b); x = add([a, b])` fused into the convolution
                         that produces a).  Needs OH, OW even and up2 = 0 */
   int32_t ldyp;
+  int32_t x_resample; /* [r06] skinny-conv layers only (dh_conv2d_uses_split_k; DH_EUNSUPPORTED elsewhere): x is not stored at the
+                         resolution H x W the convolution sees --
+                           1: x is [N, H/2, W/2, Cin] and is read as UpSampling2D((2, 2))(x)      (spnet.py:89-91: the action head's
+                              conv3 on the up-sampled class maps);
+                           2: x is [N, 2H, 2W, Cin] and is read through MaxPooling2D((2, 2));
+                           3: ... through layers.max_min_pooling((2, 2)) = max + min of the window (layers.py:411-425; spnet.py:77-79).
+                         BN / ReLU prologue and zero padding act on the resampled pixels: bit for bit the convolution of the
+                         tensor a stand-alone up-sampling / pooling launch would have written.  The field sits in what was
+                         padding in front of y_pool: a zero-initialised struct is unchanged */
   float* y_pool; /* optional second output: MaxPooling2D((2, 2)) of the convolution's FINAL output (after BN / residuals /
                     ReLU), [N, OH/2, OW/2, Cout] with pixel pitch ldyp -- the hourglass reads every level both at full and
                     at half resolution (reception.py:105-116: x = ...; MaxPooling2D((2, 2))(x)), and a stand-alone pool

@@ -250,6 +250,24 @@ def test_siblings_merged_into_joint_buffers_are_bit_identical(hip_lib, cuda, mon
             assert np.array_equal(a, b)
 
 
+def test_resample_on_load_rule_is_bit_identical(hip_lib, cuda, monkeypatch):
+    """[r06] Planner rule R12: the up-sampling in front of the action head's conv3 and the max+-min pooling in front of its
+    conv2h (spnet.py:77-91) are not written out -- the skinny-conv kernel resamples while it loads: two launches fewer per
+    head, not one bit moved (2-D and 3-D model)."""
+    clips = np.random.default_rng(35).uniform(-1, 1, (2, 8, 128, 128, 3)).astype(np.float32)
+    for layout, nact, rep in (('pa16j2d', 15, True), ('pa17j3d', 60, False)):
+        monkeypatch.setenv('DEEPHAR_RESAMPLE_ON_LOAD', '0')
+        base, _, _, _ = _spnet(8, layout, nact, 2, [1, 2], 160, replica=rep, res=128)
+        want = base.predict(clips, batch_size=2)
+        nbase = len(base.plan.steps)
+        monkeypatch.setenv('DEEPHAR_RESAMPLE_ON_LOAD', '1')
+        m, _, _, _ = _spnet(8, layout, nact, 2, [1, 2], 160, replica=rep, res=128)
+        modes = sorted(s.attrs['x_resample'] for s in m.plan.steps if s.kind == 'conv' and s.attrs.get('x_resample'))
+        assert modes == [1] * 5 + [3] * 6 and len(m.plan.steps) == nbase - 11, (modes, len(m.plan.steps), nbase)
+        for a, b in zip(want, m.predict(clips, batch_size=2)):
+            assert np.array_equal(a, b), layout
+
+
 def test_grouped_launches_are_bit_identical(hip_lib, cuda, monkeypatch):
     """[r06] BoundPlan.group_launches: at a couple of clips per call every (1x1 shortcut convolution, depthwise convolution)
     pair of SPNet's down- / up-scaling units is ONE launch (dh_conv2d_dw_group_f32) -- 2-D replica model, one and two

@@ -643,6 +643,57 @@ def test_conv2d_second_residual_at_half_resolution(case, hip_lib, cuda):
         F.conv2d(d(x), k, res2=d(r2), res2_down=True, up2=True, **kw)
 
 
+@pytest.mark.parametrize('case', [
+    # (frames, logical H, W of the conv's input, Cin, Cout, k, mode, BN prologue, ReLU prologue)
+    (16, 8, 8, 15, 160, 3, 1, False, True),       # action head conv3 on relu(UpSampling2D(class maps)): Cin = 15 (dword loads)
+    (16, 4, 4, 160, 15, 3, 3, True, True),        # action head conv2h on relu(BN(max_min_pooling(x1)))
+    (3, 8, 8, 64, 48, 3, 2, True, False),         # plain max-pooling on load
+    (2, 16, 16, 96, 200, 1, 1, False, False),     # 1x1, up-sampled input, no prologue
+    (5, 6, 10, 20, 33, 5, 3, False, True),        # 5x5, ragged everything
+    (2, 16, 16, 24, 64, 3, 2, False, True),
+])
+def test_skinny_conv_resamples_on_load(case, hip_lib, cuda):
+    """[r06] dh_conv_args.x_resample (planner rule R12): the skinny-conv kernel reads a half-resolution tensor as if
+    up-sampled (1) or a double-resolution tensor through a 2x2 max (2) / max+-min (3) pooling -- bit for bit the convolution
+    of the tensor the stand-alone up-sampling / pooling launch writes; BN / ReLU prologue and zero padding act on the
+    resampled pixels; other kernel families refuse the flag."""
+    from deephar_amd import functional as F
+    n, h, w, cin, cout, k, mode, bn, relu = case
+    rng = np.random.default_rng(sum(int(v) for v in case))
+    phys = (n, h // 2, w // 2, cin) if mode == 1 else (n, 2 * h, 2 * w, cin)
+    x = _rand(rng, phys)
+    kern = _rand(rng, (k, k, cin, cout), np.sqrt(1.0 / (k * k * cin)))
+    ps, pb = (rng.uniform(0.5, 1.5, cin).astype(np.float32), _rand(rng, (cin,), 0.4)) if bn else (None, None)
+    r1 = _rand(rng, (n, h, w, cout))
+    d = lambda a: None if a is None else torch.from_numpy(np.ascontiguousarray(a)).to(cuda)
+    if mode == 1:
+        explicit = d(np.repeat(np.repeat(x, 2, axis=1), 2, axis=2))
+    else:
+        explicit = F.pool2d(d(x), (2, 2), (2, 2), 'valid', mode=1 if mode == 3 else 0)
+    kw = dict(pre_scale=d(ps), pre_shift=d(pb), pre_relu=relu, res1=d(r1))
+    want = F.conv2d(explicit, kern, **kw)
+    got = F.conv2d(d(x), kern, x_resample=mode, **kw)
+    torch.cuda.synchronize()
+    assert got.shape == want.shape and torch.equal(got, want)
+    t = lambda a: torch.from_numpy(a).double()
+    xin = explicit.cpu().double()
+    if bn:
+        xin = xin * t(ps) + t(pb)
+    if relu:
+        xin = O.relu(xin)
+    _close(got, O.conv2d(xin, t(kern), (1, 1), 'same') + t(r1), atol=3e-5, what='resample on load')
+    half = n // 2
+    if half:
+        assert torch.equal(F.conv2d(d(x[:half]), kern, x_resample=mode, **dict(kw, res1=d(r1[:half]))), got[:half])
+
+
+def test_resampling_on_load_is_the_skinny_kernels_only(hip_lib, cuda):
+    from deephar_amd import functional as F
+    x = torch.randn(1, 32, 32, 64, device=cuda)                    # a 64 x 64 map: not a skinny layer
+    with pytest.raises(Exception, match='rc=-2'):
+        F.conv2d(x, np.zeros((3, 3, 64, 64), np.float32), x_resample=1)
+
+
 # ---- halo-resident K x K kernel (dh_conv_args.w_split = 2, conv_halo.hip) ------------------------------------------------
 HALO_CASES = [
     # n, h, w, cin, cout, kh, kw, relu prologue, residual
