@@ -574,6 +574,8 @@ def test_heat_map_head_rules_on_the_host(monkeypatch):
         cfg = ModelConfig((4, 128, 128, 3), utils.pa16j2d, num_actions=[15], num_pyramids=2, action_pyramids=[1, 2],
                           num_levels=4, pose_replica=True, num_pose_features=160, num_visual_features=160)
         return spnet.build(cfg)
+    monkeypatch.setenv('DEEPHAR_MERGE_SIBLINGS', '0')     # (round-6 rules R10b / R10c have their own test below)
+    monkeypatch.setenv('DEEPHAR_MERGE_KXK', '0')
     monkeypatch.setenv('DEEPHAR_MERGE_HEADS', '0')
     monkeypatch.setenv('DEEPHAR_CONCAT_SHARED', '0')
     base = build().plan
@@ -603,6 +605,62 @@ def test_heat_map_head_rules_on_the_host(monkeypatch):
     assert sum(s.flops() for s in plan.steps) == pytest.approx(sum(s.flops() for s in base.steps))
 
 
+def test_round6_planner_rules_on_the_host(monkeypatch):
+    """[r06] Rules R10b (K x K siblings as one centred-kernel convolution), R10c (sibling 1x1 convolutions into a joint buffer,
+    per-column affine, ReLU moved to the reader), R11 (UpSampling2D in front of an up-scaling unit: the shortcut runs at half
+    resolution as the half-resolution residual, the depthwise conv up-samples on load) and R12 (pooling / up-sampling in front
+    of a skinny-conv layer resampled on load) on the plan of the speed protocol's last model -- structure only, no GPU."""
+    import bench
+    from deephar_amd import Model, weights
+    from deephar_amd.engine.planner import ConcatAffine, ConcatParam
+
+    def plan(**env):
+        for k in ('DEEPHAR_MERGE_KXK', 'DEEPHAR_MERGE_SIBLINGS', 'DEEPHAR_UP_COMMUTE', 'DEEPHAR_RESAMPLE_ON_LOAD'):
+            monkeypatch.setenv(k, env.get(k, '1'))
+        full = bench.build_speed2d()
+        m = Model(full.input, full.outputs[34:36])
+        return m, m.plan
+    _, off = plan(DEEPHAR_MERGE_KXK='0', DEEPHAR_MERGE_SIBLINGS='0', DEEPHAR_UP_COMMUTE='0', DEEPHAR_RESAMPLE_ON_LOAD='0')
+    m, on = plan()
+    assert len(off.steps) == 604 and len(on.steps) == 473
+    # R10b: eighteen action heads, each opens with ONE 3x5 convolution of 70 columns whose parts sit centred in the window
+    kxk = [s for s in on.steps if s.kind == 'conv' and (s.name or '').count('p_conv0') == 3]
+    assert len(kxk) == 18 and all((s.attrs['kh'], s.attrs['kw'], s.attrs['pt'], s.attrs['pl'], s.attrs['Cout'], s.attrs['K']) ==
+                                  (3, 5, 1, 2, 70, 30) for s in kxk)
+    weights.init_synthetic(m, seed=0)
+    w = kxk[0].params['w']
+    assert isinstance(w, ConcatParam) and w.value.shape == (3, 5, 2, 70)
+    assert np.array_equal(w.value[:, 2:3, :, :10], w.parts[0].value) and not w.value[:, [0, 1, 3, 4], :, :10].any()
+    assert np.array_equal(w.value[:, 1:4, :, 10:30], w.parts[1].value) and not w.value[:, [0, 4], :, 10:30].any()
+    assert np.array_equal(w.value[..., 30:], w.parts[2].value)
+    # R10c: 36 residual units of the action heads (shortcut | conv1 -> 240 or 200 columns, affine on the second part, its
+    # ReLU moved to conv2's prologue), 15 replica heads beside the forward / heat-map pair (48 columns)
+    units = [s for s in on.steps if isinstance(s.params.get('post_affine'), ConcatAffine)]
+    assert len(units) == 36 and sorted({s.attrs['Cout'] for s in units}) == [200, 240] and all(not s.attrs['post_relu'] for s in units)
+    for s in units[:4]:
+        (ca, la), (cb, lb) = s.params['post_affine'].parts
+        assert la is None and lb is not None and ca == 160 and s.outs['y'].ld == ca + cb
+        reader = next(q for q in on.steps if q.kind == 'conv' and q.ins['x'].buf is s.outs['y'].buf)
+        assert reader.attrs['pre_relu'] == 1 and (reader.ins['x'].coff, reader.ins['x'].ld) == (160, ca + cb)
+        assert reader.ins['res1'].buf is s.outs['y'].buf and reader.ins['res1'].coff == 0
+    heads3 = [s for s in on.steps if s.kind == 'conv' and 'replica' in (s.name or '') and '+' in s.name]
+    assert len(heads3) == 15 and all(s.attrs['Cout'] == 48 for s in heads3)
+    # R11: nine up-scaling units -- no up-sampling launch on the pose side, shortcut at half resolution, depthwise up_in
+    assert sum(1 for s in off.steps if s.kind == 'upsample_add') == 26 and not any(s.kind == 'upsample_add' for s in on.steps)
+    up_dw = [s for s in on.steps if s.kind == 'dwconv' and s.attrs.get('up_in')]
+    assert len(up_dw) == 9 and all(s.outs['y'].shape[-3] == 2 * s.ins['x'].shape[-3] for s in up_dw)
+    down_res = [s for s in on.steps if s.kind == 'conv' and s.attrs.get('res2_down')]
+    assert len(down_res) == 9 and all(s.ins['res2'].shape[-3] * 2 == s.outs['y'].shape[-3] for s in down_res)
+    # R12: every action head's conv3 reads the class maps up-sampled on load, its conv2h reads x1 max+-min-pooled on load
+    modes = sorted(s.attrs['x_resample'] for s in on.steps if s.kind == 'conv' and s.attrs.get('x_resample'))
+    assert modes == [1] * 17 + [3] * 18
+    for s in on.steps:
+        if s.kind == 'conv' and s.attrs.get('x_resample') == 3:
+            assert s.ins['x'].shape[-3] == 2 * s.outs['y'].shape[-3]
+    # the arithmetic that is left: the up-scaling shortcuts run on a quarter of the pixels, nothing else changed
+    assert sum(s.flops() for s in on.steps) < sum(s.flops() for s in off.steps)
+
+
 def test_speed_protocol_configuration_is_the_reference_script():
     """bench.build_speed2d = exp/pennaction/eval_speed2d.py:31-36,50: six pyramids, actions on all six, pose_replica, 8-frame
     clips, 160 features; 18 pose + 18 action outputs, and the truncated model of block b is outputs[2b:2b+2]."""
@@ -617,5 +675,5 @@ def test_speed_protocol_configuration_is_the_reference_script():
     assert [o.shape for o in full.outputs[:npred]] == [(8, 16, 3)] * npred and [o.shape for o in full.outputs[npred:]] == [(15,)] * npred
     last = Model(full.input, full.outputs[2 * (npred - 1):2 * npred])
     first = Model(full.input, full.outputs[0:2])
-    assert len(first.plan.steps) < 50 < 500 < len(last.plan.steps)
+    assert len(first.plan.steps) < 50 < 400 < len(last.plan.steps)
     assert bench.WORKLOADS['speed2d']['per_gpu'] == 2 and bench.WORKLOADS['speed2d']['T'] == 8
