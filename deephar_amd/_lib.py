@@ -41,7 +41,7 @@ class EltArgs(C.Structure):
 class SamArgs(C.Structure):
     _fields_ = [(n, vp) for n in ('h', 'gx', 'gy', 'xy', 'conf_raw', 'conf_prob', 'prob', 'gmax')] + \
                [(n, i32) for n in ('F', 'H', 'W', 'C', 'ldh', 'ldxy', 'ldcr', 'ldcp', 'ldp')] + \
-               [('alpha', C.c_float), ('conf_scale', C.c_float)]
+               [('alpha', C.c_float), ('conf_scale', C.c_float), ('xy_times_conf', i32)]
 
 
 # name -> (restype, argtypes); every symbol include/deephar_hip.h declares

@@ -13,6 +13,7 @@ static inline hipStream_t S(void* s) { return reinterpret_cast<hipStream_t>(s); 
 static_assert(sizeof(dh_conv_args) == 200 && offsetof(dh_conv_args, y_pool) == 192 && offsetof(dh_conv_args, x_resample) == 188,
               "dh_conv_args layout");
 static_assert(sizeof(dh_dw_args) == 88 && offsetof(dh_dw_args, up_in) == 84, "dh_dw_args layout");
+static_assert(sizeof(dh_sam_args) == 112 && offsetof(dh_sam_args, xy_times_conf) == 108, "dh_sam_args layout");
 static inline int rc_of(hipError_t e) { return e == hipSuccess ? DH_OK : DH_ELAUNCH; }
 
 extern "C" {

@@ -143,7 +143,7 @@ __global__ __launch_bounds__(NTH) void softargmax2d_kernel(const SamArgs p) {
       s += e;
       sx = fmaf(e, STAGED ? sgx[q] : p.gx[q], sx);
       sy = fmaf(e, STAGED ? sgy[r] : p.gy[r], sy);
-      if (p.conf_prob != nullptr && r + 1 < p.H && q + 1 < p.W) {
+      if ((p.conf_prob != nullptr || p.xy_times_conf) && r + 1 < p.H && q + 1 < p.W) {
         const float e1 = expf(p.alpha * at(px + 1) - vmax);
         const float e2 = expf(p.alpha * at(px + p.W) - vmax);
         const float e3 = expf(p.alpha * at(px + p.W + 1) - vmax);
@@ -167,8 +167,14 @@ __global__ __launch_bounds__(NTH) void softargmax2d_kernel(const SamArgs p) {
   if (cok && pl == 0) {
     if (p.xy != nullptr) {
       float* o = p.xy + ((size_t)f * p.C + c) * p.ldxy;
-      o[0] = sx * inv;
-      o[1] = sy * inv;
+      float ox = sx * inv, oy = sy * inv;
+      if (p.xy_times_conf) {        // multiply([p, c]) of spnet.py:108 folded in: the two fp32 values a stand-alone launch would
+        const float cf = pmax * inv;   // read back, one multiplication each
+        ox *= cf;
+        oy *= cf;
+      }
+      o[0] = ox;
+      o[1] = oy;
     }
     if (p.conf_raw != nullptr) p.conf_raw[((size_t)f * p.C + c) * p.ldcr] = cmax;
     if (p.conf_prob != nullptr) p.conf_prob[((size_t)f * p.C + c) * p.ldcp] = pmax * inv;

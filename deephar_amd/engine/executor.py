@@ -348,6 +348,7 @@ class BoundPlan:
                 args.gmax = P(o['gmax'])
             args.F, args.H, args.W, args.C, args.ldh = n * h.lead(3), H, W, h.C, h.ld
             args.alpha, args.conf_scale = a['alpha'], a['conf_scale']
+            args.xy_times_conf = a.get('xy_times_conf', 0)
             self._keep.append(args)
             self.calls.append((lib.dh_softargmax2d_f32, (C.byref(args),), s))
         elif k == 'sam_ctx':

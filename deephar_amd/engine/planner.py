@@ -1123,6 +1123,23 @@ class Planner:
                 self.val[p_t.uid] = None  # never read
             if sm is not softmax_node:
                 self.absorbed.add(sm.uid)
+        # [r06] multiply([p, c]) right behind a read-out whose coordinates and confidence have no other reader (the replica
+        # read-out in front of an action head, spnet.py:108) is folded into it: xy receives (x, y) * confidence
+        if os.environ.get('DEEPHAR_FOLD_POSE_MUL', '1') != '0' and len(twins) == 1 and 'xy' in outs and 'conf_prob' in outs:
+            xy_t = next((n.outputs[0] for n, _ in self.consumers.get(twins[0].outputs[0].uid, []) if n.op == 'expect2d'), None)
+            cf_t = next((n.outputs[0] for n, _ in self.consumers.get(twins[0].outputs[0].uid, []) if n.op == 'jointprob'), None)
+            mul = self.sole_consumer(xy_t, 'mul') if xy_t is not None else None
+            if mul is not None and cf_t is not None and self.sole_consumer(cf_t, 'mul') is mul and \
+                    [t.uid for t in mul.inputs] == [xy_t.uid, cf_t.uid] and outs['xy'].dense and outs['conf_prob'].dense:
+                for v in (outs['xy'], outs['conf_prob']):             # the two intermediate tensors are never written
+                    if v.buf in self.plan.bufs:
+                        self.plan.bufs.remove(v.buf)
+                outs['xy'] = self.out_value_for(mul.outputs[0])
+                del outs['conf_prob']
+                attrs['xy_times_conf'] = 1
+                self.val[mul.outputs[0].uid] = outs['xy']
+                self.val[xy_t.uid] = self.val[cf_t.uid] = None
+                self.absorbed.add(mul.uid)
         if prob_users:
             outs['prob'] = self.out_value_for(prob_users[0]) if len(prob_users) == 1 else \
                 self.new_value(prob_users[0].shape)

@@ -240,6 +240,10 @@ typedef struct dh_sam_args {
   int32_t F, H, W, C, ldh, ldxy, ldcr, ldcp, ldp;
   float alpha;
   float conf_scale;
+  int32_t xy_times_conf; /* [r06] 1: xy receives (x, y) * conf_prob -- `multiply([p, c])` in front of the action head's pose
+                            convolutions (spnet.py:108) folded into the read-out that produces both factors (the same two
+                            fp32 values, one multiplication each: bit-identical); conf_prob itself may be NULL.  The field sits
+                            in what was tail padding of the struct */
 } dh_sam_args;
 int dh_softargmax2d_f32(const dh_sam_args* a, void* stream);
 

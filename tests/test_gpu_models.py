@@ -268,6 +268,24 @@ def test_resample_on_load_rule_is_bit_identical(hip_lib, cuda, monkeypatch):
             assert np.array_equal(a, b), layout
 
 
+def test_pose_times_confidence_folded_into_the_read_out(hip_lib, cuda, monkeypatch):
+    """[r06] multiply([p, c]) in front of an action head (spnet.py:108) on a replica read-out whose coordinates and confidence
+    have no other reader is folded into the soft-argmax launch (dh_sam_args.xy_times_conf): one launch less per head, the same
+    bits (the same two fp32 factors, one multiplication); the 3-D model (pose = concat(xy, z), also a model output) keeps its
+    multiply."""
+    clips = np.random.default_rng(37).uniform(-1, 1, (2, 8, 128, 128, 3)).astype(np.float32)
+    for layout, nact, rep, folded in (('pa16j2d', 15, True, 6), ('pa17j3d', 60, False, 0)):
+        monkeypatch.setenv('DEEPHAR_FOLD_POSE_MUL', '0')
+        base, _, _, _ = _spnet(8, layout, nact, 2, [1, 2], 160, replica=rep, res=128)
+        want = base.predict(clips, batch_size=2)
+        monkeypatch.setenv('DEEPHAR_FOLD_POSE_MUL', '1')
+        m, _, _, _ = _spnet(8, layout, nact, 2, [1, 2], 160, replica=rep, res=128)
+        assert sum(1 for s in m.plan.steps if s.kind == 'sam' and s.attrs.get('xy_times_conf')) == folded
+        assert len(m.plan.steps) == len(base.plan.steps) - folded
+        for a, b in zip(want, m.predict(clips, batch_size=2)):
+            assert np.array_equal(a, b), layout
+
+
 def test_grouped_launches_are_bit_identical(hip_lib, cuda, monkeypatch):
     """[r06] BoundPlan.group_launches: at a couple of clips per call every (1x1 shortcut convolution, depthwise convolution)
     pair of SPNet's down- / up-scaling units is ONE launch (dh_conv2d_dw_group_f32) -- 2-D replica model, one and two

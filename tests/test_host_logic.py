@@ -615,14 +615,15 @@ def test_round6_planner_rules_on_the_host(monkeypatch):
     from deephar_amd.engine.planner import ConcatAffine, ConcatParam
 
     def plan(**env):
-        for k in ('DEEPHAR_MERGE_KXK', 'DEEPHAR_MERGE_SIBLINGS', 'DEEPHAR_UP_COMMUTE', 'DEEPHAR_RESAMPLE_ON_LOAD'):
+        for k in ('DEEPHAR_MERGE_KXK', 'DEEPHAR_MERGE_SIBLINGS', 'DEEPHAR_UP_COMMUTE', 'DEEPHAR_RESAMPLE_ON_LOAD', 'DEEPHAR_FOLD_POSE_MUL'):
             monkeypatch.setenv(k, env.get(k, '1'))
         full = bench.build_speed2d()
         m = Model(full.input, full.outputs[34:36])
         return m, m.plan
-    _, off = plan(DEEPHAR_MERGE_KXK='0', DEEPHAR_MERGE_SIBLINGS='0', DEEPHAR_UP_COMMUTE='0', DEEPHAR_RESAMPLE_ON_LOAD='0')
+    _, off = plan(DEEPHAR_MERGE_KXK='0', DEEPHAR_MERGE_SIBLINGS='0', DEEPHAR_UP_COMMUTE='0', DEEPHAR_RESAMPLE_ON_LOAD='0',
+                  DEEPHAR_FOLD_POSE_MUL='0')
     m, on = plan()
-    assert len(off.steps) == 604 and len(on.steps) == 473
+    assert len(off.steps) == 604 and len(on.steps) == 455
     # R10b: eighteen action heads, each opens with ONE 3x5 convolution of 70 columns whose parts sit centred in the window
     kxk = [s for s in on.steps if s.kind == 'conv' and (s.name or '').count('p_conv0') == 3]
     assert len(kxk) == 18 and all((s.attrs['kh'], s.attrs['kw'], s.attrs['pt'], s.attrs['pl'], s.attrs['Cout'], s.attrs['K']) ==
@@ -657,6 +658,9 @@ def test_round6_planner_rules_on_the_host(monkeypatch):
     for s in on.steps:
         if s.kind == 'conv' and s.attrs.get('x_resample') == 3:
             assert s.ins['x'].shape[-3] == 2 * s.outs['y'].shape[-3]
+    # the replica read-outs write (x, y) * confidence themselves: no multiply launch is left
+    assert sum(1 for s in off.steps if s.kind == 'eltwise') == 18 and not any(s.kind == 'eltwise' for s in on.steps)
+    assert sum(1 for s in on.steps if s.kind == 'sam' and s.attrs.get('xy_times_conf')) == 18
     # the arithmetic that is left: the up-scaling shortcuts run on a quarter of the pixels, nothing else changed
     assert sum(s.flops() for s in on.steps) < sum(s.flops() for s in off.steps)
 
@@ -675,5 +679,5 @@ def test_speed_protocol_configuration_is_the_reference_script():
     assert [o.shape for o in full.outputs[:npred]] == [(8, 16, 3)] * npred and [o.shape for o in full.outputs[npred:]] == [(15,)] * npred
     last = Model(full.input, full.outputs[2 * (npred - 1):2 * npred])
     first = Model(full.input, full.outputs[0:2])
-    assert len(first.plan.steps) < 50 < 400 < len(last.plan.steps)
+    assert len(first.plan.steps) < 50 < 400 < len(last.plan.steps) < 480
     assert bench.WORKLOADS['speed2d']['per_gpu'] == 2 and bench.WORKLOADS['speed2d']['T'] == 8
