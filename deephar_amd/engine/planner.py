@@ -607,6 +607,9 @@ class Planner:
                 if any(v is not None and v.buf is y.buf for q in steps if q is not st for v in q.outs.values()):
                     return False
             # this pass is for the skinny-conv family (16-column tiles: any widths tile together as well as apart)
+            # (round 6 re-measured the wide case on the one pair whose joint width is a whole number of 32-column tiles,
+            # SPNet-NTU's res1 shortcut | conv1 = 192 + 96 columns at 64 x 64 x 256 frames: 613.7 us merged against 392.3 +
+            # 214.8 us apart, 22.26 against 22.21 ms per step -- the second read of the input comes from the memory-side cache)
             if not (family(a, ya.C) and family(b, yb.C) and family(a, ya.C + yb.C)):
                 return False
             for st in (a, b):                 # readers must take (pointer, pitch) views
