@@ -20,6 +20,8 @@
 // The K order differs from the other conv kernels (NWV partial sums over contiguous K runs), so this kernel is picked
 // by a SHAPE rule (conv_is_skinny: per-frame geometry only), never by timing, batch size or alignment, and the number
 // of waves follows from K alone: a layer always computes the same bits.
+#include <cstdlib>
+
 #include "conv_common.h"
 
 namespace dh {
@@ -257,7 +259,9 @@ bool conv_is_skinny(const ConvArgs& a) {
   if (a.x_u8 || a.w_split) return false;
   // kernel extent: `locate` decodes tap -> (kh, kw) as (tap * magic_kw) >> 16, exact while tap * KW < 2^16 -- KH * KW < 256
   // keeps tap < 256 and KW < 256 (KW < 256 alone admitted KW = 255, KH >= 2, where tap >= 258 decodes wrong)
-  return a.OH * a.OW <= 256 && a.K >= 64 && a.Cout <= 256 && a.Cin >= 2 && a.Cin <= SK_MAX_CIN && a.KH >= 1 && a.KW >= 1 &&
+  // DEEPHAR_SKINNY_MIN_K: A/B aid for the rule's K threshold (read once; planner.split_k_rule reads the same variable)
+  static const int min_k = [] { const char* e = getenv("DEEPHAR_SKINNY_MIN_K"); return e != nullptr ? atoi(e) : 64; }();
+  return a.OH * a.OW <= 256 && a.K >= min_k && a.Cout <= 256 && a.Cin >= 2 && a.Cin <= SK_MAX_CIN && a.KH >= 1 && a.KW >= 1 &&
          (long long)a.KH * a.KW < 256 && (long long)a.K * a.Cin < (1ll << 31);
 }
 

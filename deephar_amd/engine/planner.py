@@ -83,7 +83,10 @@ def split_k_rule(out_pixels, K, cout, cin, kh=1, kw=1):
     the layers dh_conv2d_f32 runs on its in-work-group split-K kernel -- per-frame geometry only, so a layer's bits depend
     on neither batch size nor tiling.  Every clause of the C++ rule is stated here (the two had drifted apart
     on the kernel-extent clauses); tests/test_host_logic.py sweeps both over the same shapes."""
-    return out_pixels <= 256 and K >= 64 and cout <= 256 and 2 <= cin <= 4096 and kh * kw < 256 and K * cin < (1 << 31)
+    return out_pixels <= 256 and K >= _SKINNY_MIN_K and cout <= 256 and 2 <= cin <= 4096 and kh * kw < 256 and K * cin < (1 << 31)
+
+
+_SKINNY_MIN_K = int(os.environ.get('DEEPHAR_SKINNY_MIN_K', '64'))      # (A/B aid, read once like the library's copy)
 
 
 class ConcatParam:
