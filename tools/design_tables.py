@@ -6,11 +6,11 @@ hand-copied parity table had drifted from profiles/parity_r04.json by 3.5x).
     python tools/design_tables.py --check    # exit 1 if DESIGN.md is not what the records say (tests/test_host_logic.py)
 
 Blocks:
-  parity      worst |hip - o64|, |o32 - o64|, |hip - o32| per BASELINE configuration, from profiles/parity_r05.json
+  parity      worst |hip - o64|, |o32 - o64|, |hip - o32| per BASELINE configuration, from profiles/parity_r06.json
   workloads   frames/s, ms per step, dominant launch shape + its fraction of the fp32 MFMA peak, whole-forward fraction,
-              PMC traffic / algorithmic bytes, CPU stand-in -- from profiles/r05_bench_line_<workload>.json
-  speed2d     the reference's own speed protocol (exp/pennaction/eval_speed2d.py): fps per prediction block, first
-              measurement of the round beside the last
+              PMC traffic / algorithmic bytes, CPU stand-in -- from profiles/r06_bench_line_<workload>.json
+  speed2d     the reference's own speed protocol (exp/pennaction/eval_speed2d.py): fps per prediction block, the end of the
+              previous round beside the end of this one
 """
 import json
 import os
@@ -19,7 +19,8 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 P = os.path.join(ROOT, 'profiles')
-ROUND = 'r05'
+ROUND = 'r06'
+PREV = 'r05'
 
 
 def _load(name):
@@ -41,6 +42,12 @@ PARITY_ROWS = [
     ('NTU SPNet, T = 32 (configs[4]), fitted heads, 3 seeds x 2 clips, fp32', lambda c: c.startswith('spnet_flat/cfg5_ntu_T32') and c.endswith('/f32')),
     ('the same against the REFERENCE CODE golden at T = 32 / 256 px (`spnet3d_32_s`), fp32', lambda c: c == 'spnet_flat_golden/spnet3d_32_s/f32'),
     ('SPNet shipped Penn config (replica), fitted heads, 3 seeds x 2 clips, fp32', lambda c: c.startswith('spnet_flat/penn_shipped') and c.endswith('/f32')),
+    ('the speed protocol\'s model (eval_speed2d.py: 6 pyramids, actions on all six, replica), fitted heads, 3 seeds x 2 clips, fp32',
+     lambda c: c.startswith('spnet_flat/speed2d') and c.endswith('/f32')),
+    ('the same against the REFERENCE CODE golden at its real size (`spnet2d_speed_s`): full model under 1 / 2 / 3 streams',
+     lambda c: c.startswith('speed2d_golden/full/')),
+    ('... and every truncated model of the protocol (18 blocks x {1 stream, 2 streams \'tail\'}, two clips per call)',
+     lambda c: c.startswith('speed2d_golden/truncated/')),
     ('every SPNet configuration, `bf16x3` mode', lambda c: c.startswith('spnet_flat') and c.endswith('/bf16x3')),
     ('ReceptionNet configurations, `bf16x3` mode (tests/test_gpu_bf16x3.py)', lambda c: 'test_gpu_bf16x3' in c),
 ]
@@ -86,16 +93,17 @@ def workloads_block():
 
 
 def speed2d_block():
-    first = _load('%s_speed2d_first_bench_line.json' % ROUND)
+    first = _load('%s_bench_line_speed2d.json' % PREV)
     last = _load('%s_bench_line_speed2d.json' % ROUND)
     f, l = first['speed2d'], last['speed2d']
     lines = ['| prediction block b (outputs 2b, 2b + 1) | ' + ' | '.join(str(b) for b in l['blocks']) + ' |',
              '|---|' + '---|' * len(l['blocks']),
-             '| launches per call | ' + ' | '.join(str(v) for v in l['launches_per_call']) + ' |',
-             '| frames/s, first measurement of the round | ' + ' | '.join('%.0f' % f['fps_per_block'][f['blocks'].index(b)] for b in l['blocks']) + ' |',
-             '| frames/s, end of the round | ' + ' | '.join('%.0f' % v for v in l['fps_per_block']) + ' |',
+             '| launches per call, end of round 5 | ' + ' | '.join(str(f['launches_per_call'][f['blocks'].index(b)]) for b in l['blocks']) + ' |',
+             '| launches per call, end of round 6 | ' + ' | '.join(str(v) for v in l['launches_per_call']) + ' |',
+             '| frames/s, end of round 5 | ' + ' | '.join('%.0f' % f['fps_per_block'][f['blocks'].index(b)] for b in l['blocks']) + ' |',
+             '| frames/s, end of round 6 | ' + ' | '.join('%.0f' % v for v in l['fps_per_block']) + ' |',
              '| ratio | ' + ' | '.join('%.2f' % (v / f['fps_per_block'][f['blocks'].index(b)]) for b, v in zip(l['blocks'], l['fps_per_block'])) + ' |',
-             '| fraction of the fp32 MFMA peak, end of the round | ' + ' | '.join('%.3f' % v for v in l['whole_forward_frac_per_block']) + ' |',
+             '| fraction of the fp32 MFMA peak, end of round 6 | ' + ' | '.join('%.3f' % v for v in l['whole_forward_frac_per_block']) + ' |',
              '',
              'Device-resident step of the last block\'s model (2 clips = 16 frames): **%.2f ms → %.2f ms (× %.2f)**, %.0f → %.0f '
              'frames/s; `predict` on host arrays, last block: %.0f → %.0f frames/s; CPU stand-in on this host: %s frames/s.' % (
