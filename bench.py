@@ -1055,7 +1055,15 @@ def main():
                          out=list(next(iter(s.outs.values())).shape) if s.outs else None) for s, ms, n in rows]
             with open(args.dump_steps, 'w') as f:
                 json.dump(dump, f, indent=1)
-        print(json.dumps(out))
+        # RCCL writes its version banner through C stdio, which a redirected stdout holds back until exit -- behind the JSON
+        # line.  Flush it first: the contract line is the LAST line this process prints.
+        sys.stdout.flush()
+        try:
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except OSError:
+            pass
+        print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
     if world > 1 or args.force_collective:

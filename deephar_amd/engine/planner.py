@@ -481,6 +481,7 @@ class Planner:
             self.plan.outputs.append(v)
         self._merge_sibling_pointwise()
         self._merge_siblings_into_joint_buffers()
+        self._merge_sibling_pools()
         self._collect_params()
         from . import schedule
         schedule.finalize(self.plan, self.nstreams, self.stream_policy)
@@ -675,6 +676,68 @@ class Planner:
             steps[i] = merged
             for v in (ya, yb, y):
                 self.producer[id(v)] = merged
+
+    # ---- R13: sibling poolings that fill neighbouring channel slabs of one buffer ---------------------------------
+    def _merge_sibling_pools(self):
+        """[r06] The action head pools its pose features and its appearance features with the same window and concatenates the
+        results right away (spnet.py:126-139: `x1 = maxpooling2d(x, (2, 2), strides=(time_stride, 2))`, `x2 = maxpooling2d(...)`,
+        `concat_tensorlist([x1, x2, xa])`): two launches over two [frames, joints, 160] tensors.  Their producers write the two
+        channel runs of ONE joint buffer instead and a single pooling launch covers both -- pooling is per channel, so every
+        output element is the maximum of the same values.  Bit-identical; one launch less per action head (the latency
+        regime: a node costs ~5 us whatever it moves).  DEEPHAR_MERGE_POOLS=0 switches it off."""
+        if os.environ.get('DEEPHAR_MERGE_POOLS', '1') == '0':
+            return
+        steps = self.plan.steps
+
+        def sole_buffer(st):
+            """the pool's input fills its own buffer, one step writes it, the pool alone reads it"""
+            x = st.ins['x']
+            if x.coff != 0 or x.ld != x.C or x.buf.pinned or x.buf.kind != 'act' or \
+                    x.buf.items != (int(np.prod(x.shape)) + 3) // 4 * 4:
+                return False
+            writers = [q for q in steps for v in q.outs.values() if v is not None and v.buf is x.buf]
+            readers = [q for q in steps for v in q.ins.values() if v is not None and v.buf is x.buf]
+            return len(writers) == 1 and readers == [st] and all(v.coff == 0 and v.ld == x.C for v in writers[0].outs.values()
+                                                                if v is not None and v.buf is x.buf)
+
+        i = 0
+        while i < len(steps):
+            a = steps[i]
+            j = None
+            if a.kind == 'pool' and sole_buffer(a):
+                xa, ya = a.ins['x'], a.outs['y']
+                for jj in range(i + 1, len(steps)):
+                    b = steps[jj]
+                    if b.kind != 'pool' or b.attrs != a.attrs:
+                        continue
+                    xb, yb = b.ins['x'], b.outs['y']
+                    if yb.buf is ya.buf and yb.ld == ya.ld and yb.coff == ya.coff + ya.C and yb.shape[:-1] == ya.shape[:-1] and \
+                            xb.shape[:-1] == xa.shape[:-1] and xb.buf is not xa.buf and sole_buffer(b) and \
+                            not any(v is not None and v.buf is ya.buf for q in steps[i + 1:jj] for v in q.ins.values()):
+                        j = jj
+                        break
+            if j is None:
+                i += 1
+                continue
+            b = steps[j]
+            xb, yb = b.ins['x'], b.outs['y']
+            ca, cb = xa.C, xb.C
+            joint = self.new_buf(xa.shape[:-1] + (ca + cb,))
+            for old, base in ((xa.buf, 0), (xb.buf, ca)):
+                for q in steps:
+                    for v in list(q.ins.values()) + list(q.outs.values()):
+                        if v is not None and v.buf is old:
+                            v.buf, v.coff, v.ld = joint, v.coff + base, ca + cb
+                self.plan.bufs.remove(old)
+            x = Value(xa.shape[:-1] + (ca + cb,), joint, 0, ca + cb)
+            y = Value(ya.shape[:-1] + (ya.C + yb.C,), ya.buf, ya.coff, ya.ld)
+            merged = Step('pool', dict(x=x), dict(y=y), dict(a.attrs), {}, '%s+%s' % (a.name, b.name))
+            # at the LATER pool's place: both producers have run by then, and nothing in between reads the first slab
+            steps[j] = merged
+            del steps[i]
+            for v in (ya, yb, y):
+                self.producer[id(v)] = merged
+            # (the merged step may pair again with a third sibling further down; i now holds the next step)
 
     # ---- R3: add([a, UpSampling2D(b)]) as the second residual of the convolution that produces a --------------
     def _upsampled_residual(self, t):

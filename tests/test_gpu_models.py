@@ -268,6 +268,29 @@ def test_resample_on_load_rule_is_bit_identical(hip_lib, cuda, monkeypatch):
             assert np.array_equal(a, b), layout
 
 
+def test_sibling_pools_merged_are_bit_identical(hip_lib, cuda, monkeypatch):
+    """[r06] Planner rule R13: the action head's two poolings (pose features, appearance features: spnet.py:126-133) read one
+    joint buffer their producers fill and run as ONE launch into the concatenation: one launch less per head, not one bit
+    moved -- 2-D replica model and 3-D model, one and two streams, 8-frame clips (window stride (1, 2)) and 16-frame clips
+    (stride (2, 2))."""
+    for frames, seed in ((8, 41), (16, 43)):
+        clips = np.random.default_rng(seed).uniform(-1, 1, (2, frames, 128, 128, 3)).astype(np.float32)
+        for layout, nact, rep in (('pa16j2d', 15, True), ('pa17j3d', 60, False)):
+            monkeypatch.setenv('DEEPHAR_MERGE_POOLS', '0')
+            base, _, _, _ = _spnet(frames, layout, nact, 2, [1, 2], 160, replica=rep, res=128)
+            want = base.predict(clips, batch_size=2)
+            nbase = len(base.plan.steps)
+            monkeypatch.setenv('DEEPHAR_MERGE_POOLS', '1')
+            for streams, policy in ((1, 'list'), (2, 'tail')):
+                m, _, _, _ = _spnet(frames, layout, nact, 2, [1, 2], 160, replica=rep, res=128)
+                m.num_streams, m.stream_policy = streams, policy
+                joint = [s for s in m.plan.steps if s.kind == 'pool' and '+' in (s.name or '')]
+                assert len(joint) == 6 and len(m.plan.steps) == nbase - 6, (len(joint), len(m.plan.steps), nbase)
+                assert all(s.ins['x'].C == 320 and s.ins['x'].ld == 320 and s.outs['y'].C == 320 for s in joint)
+                for a, b in zip(want, m.predict(clips, batch_size=2)):
+                    assert np.array_equal(a, b), (frames, layout, streams)
+
+
 def test_pose_times_confidence_folded_into_the_read_out(hip_lib, cuda, monkeypatch):
     """[r06] multiply([p, c]) in front of an action head (spnet.py:108) on a replica read-out whose coordinates and confidence
     have no other reader is folded into the soft-argmax launch (dh_sam_args.xy_times_conf): one launch less per head, the same

@@ -615,15 +615,16 @@ def test_round6_planner_rules_on_the_host(monkeypatch):
     from deephar_amd.engine.planner import ConcatAffine, ConcatParam
 
     def plan(**env):
-        for k in ('DEEPHAR_MERGE_KXK', 'DEEPHAR_MERGE_SIBLINGS', 'DEEPHAR_UP_COMMUTE', 'DEEPHAR_RESAMPLE_ON_LOAD', 'DEEPHAR_FOLD_POSE_MUL'):
+        for k in ('DEEPHAR_MERGE_KXK', 'DEEPHAR_MERGE_SIBLINGS', 'DEEPHAR_UP_COMMUTE', 'DEEPHAR_RESAMPLE_ON_LOAD', 'DEEPHAR_FOLD_POSE_MUL',
+                  'DEEPHAR_MERGE_POOLS'):
             monkeypatch.setenv(k, env.get(k, '1'))
         full = bench.build_speed2d()
         m = Model(full.input, full.outputs[34:36])
         return m, m.plan
     _, off = plan(DEEPHAR_MERGE_KXK='0', DEEPHAR_MERGE_SIBLINGS='0', DEEPHAR_UP_COMMUTE='0', DEEPHAR_RESAMPLE_ON_LOAD='0',
-                  DEEPHAR_FOLD_POSE_MUL='0')
+                  DEEPHAR_FOLD_POSE_MUL='0', DEEPHAR_MERGE_POOLS='0')
     m, on = plan()
-    assert len(off.steps) == 604 and len(on.steps) == 455
+    assert len(off.steps) == 604 and len(on.steps) == 437
     # R10b: eighteen action heads, each opens with ONE 3x5 convolution of 70 columns whose parts sit centred in the window
     kxk = [s for s in on.steps if s.kind == 'conv' and (s.name or '').count('p_conv0') == 3]
     assert len(kxk) == 18 and all((s.attrs['kh'], s.attrs['kw'], s.attrs['pt'], s.attrs['pl'], s.attrs['Cout'], s.attrs['K']) ==
@@ -661,6 +662,13 @@ def test_round6_planner_rules_on_the_host(monkeypatch):
     # the replica read-outs write (x, y) * confidence themselves: no multiply launch is left
     assert sum(1 for s in off.steps if s.kind == 'eltwise') == 18 and not any(s.kind == 'eltwise' for s in on.steps)
     assert sum(1 for s in on.steps if s.kind == 'sam' and s.attrs.get('xy_times_conf')) == 18
+    # R13: every action head pools its pose and appearance features in one launch out of a joint buffer
+    pools = [s for s in on.steps if s.kind == 'pool' and '+' in (s.name or '')]
+    assert len(pools) == 18 and all(s.ins['x'].shape == (8, 16, 320) and s.outs['y'].shape == (8, 8, 320) for s in pools)
+    for s in pools[:3]:
+        writers = [q for q in on.steps for v in q.outs.values() if v is not None and v.buf is s.ins['x'].buf]
+        assert sorted((v.coff, v.C) for q in writers for v in q.outs.values() if v.buf is s.ins['x'].buf) == [(0, 160), (160, 160)]
+        assert all(on.steps.index(q) < on.steps.index(s) for q in writers)
     # the arithmetic that is left: the up-scaling shortcuts run on a quarter of the pixels, nothing else changed
     assert sum(s.flops() for s in on.steps) < sum(s.flops() for s in off.steps)
 

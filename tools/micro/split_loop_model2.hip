@@ -145,5 +145,12 @@ int main() {
   run<2, 10, 76, 7, true, 0, 256, true>(2, "32x192 4w x2 bk16 spread");
   run<2, 10, 76, 0, true, 0, 256, true>(2, "32x192 4w x2 bk16 no dma");
   run<2, 10, 76, 7, true, 1, 256, true>(2, "32x192 4w x2 bk16 spread hbm");
+  // [r06] VERDICT r05 item 6 priced: the activations arrive PRE-SPLIT (three bf16 planes written by the producer's epilogue:
+  // 6 bytes per element instead of 4) -- no split VALU in the K loop, one more LDS-DMA piece per wave and 16-k K-step
+  // (A stage 3 KiB instead of 2 KiB per wave), one more ds_read_b128 per chunk (11 instead of 10 per half in this model)
+  run<2, 11, 0, 8, true, 0, 256, true>(2, "pre-split A: bk16 spread l2");
+  run<2, 11, 0, 8, true, 1, 256, true>(2, "pre-split A: bk16 spread hbm");
+  run<2, 10, 0, 7, true, 0, 256, true>(2, "(no split VALU, nothing else) l2");
+  run<2, 10, 0, 7, true, 1, 256, true>(2, "(no split VALU, nothing else) hbm");
   return 0;
 }
