@@ -146,6 +146,15 @@ struct EpiPrefetch {
 // block = one image row at OW == 32, and the waves come in (even, odd) pairs over M.
 template <int WM, int TM, bool UP2>
 constexpr bool conv_epilogue_pools() { return TM == 1 && WM % 2 == 0 && !UP2; }
+// [r06] OW == 16 / OW == 8: a wave's 32-row block is two / four WHOLE image rows (OH * OW a multiple of 32, so a block
+// never straddles frames and starts at an even row) -- the wave pools its own slab, no partner needed: any TM == 1 tiling.
+template <int TM, bool UP2>
+constexpr bool conv_epilogue_pools_in_wave() { return TM == 1 && !UP2; }
+// launch-side: may this tiling serve a.y_pool?
+template <int WM, int TM, bool UP2>
+inline bool conv_epilogue_pools_for(const ConvArgs& a) {
+  return a.OW == 32 ? conv_epilogue_pools<WM, TM, UP2>() : conv_epilogue_pools_in_wave<TM, UP2>();
+}
 
 struct EpiNoHook {
   __device__ __forceinline__ void operator()() const {}
@@ -169,6 +178,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x16 (&acc)[T
   constexpr int NSC = (64 % ROW4 == 0) ? 1 : 3;   // distinct column groups a lane meets over the row loop
   constexpr bool kPre = PRE && EpiPrefetch<TM, TN>::kEnabled;
   constexpr bool kPool = conv_epilogue_pools<WM, TM, UP2>();
+  constexpr bool kPoolWave = conv_epilogue_pools_in_wave<TM, UP2>();
   if constexpr (!UP2 && kPre && std::is_same<HOOK, EpiNoHook>::value) {
     if (EpiPrefetch<TM, TN>::template direct_tile<WM, WN>(p, m0, n0, M, epi_vec)) {
       // Direct path (interior tiles of plain launches): no LDS staging, no work-group barrier, no wait between the last
@@ -349,7 +359,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x16 (&acc)[T
               o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f);
             }
             if (ok) st4_stream(p.y + mo[u][d] * p.ldy + nc, o);
-            if constexpr (kPool) {                                 // keep the final values: the pair pools them below
+            if constexpr (kPool || kPoolWave) {                    // keep the final values: they are pooled below
               if (p.y_pool != nullptr) *reinterpret_cast<float4*>(&sC[row * LDC + c4 * 4]) = o;
             }
           }
@@ -403,7 +413,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x16 (&acc)[T
   if constexpr (kPool) {
     // MaxPooling2D((2, 2)) of what was just stored: the slabs now hold the FINAL values of the work-group's image rows
     // (OW == 32: one row per wave); waves (2i, 2i+1) over M pool their two rows, 128 threads per pair
-    if (p.y_pool != nullptr && vec) {
+    if (p.y_pool != nullptr && vec && p.OW == 32) {
       __syncthreads();
       const float* sE = smem + ((wm & ~1) * WN + wn) * 32 * LDC;
       const float* sO = sE + WN * 32 * LDC;
@@ -427,6 +437,37 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x16 (&acc)[T
       }
       __syncthreads();      // a kernel that runs this epilogue again through the same slabs (the split wide tiling's second
                             // column slice) must not stage over rows its partner wave is still pooling
+    }
+  }
+  if constexpr (kPoolWave) {
+    // [r06] the same at OW == 16 / 8 (SPNet's down path below 32 x 32, common.py:70-86; the hourglass's inner levels): the
+    // wave's slab holds 2 / 4 whole image rows = 8 pooled pixels; wave-private, so no barrier -- only the slab writes above
+    // have to have landed
+    if (p.y_pool != nullptr && vec && p.OW < 32) {
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      const int mb = m0 + wm * 32;
+      if (mb + 32 <= M) {
+        const int pw_sh = __ffs(p.OW) - 2;                       // log2(OW / 2)
+        const int row0 = mb >> (pw_sh + 1);                      // image row of the block's first pixel (even)
+        const int fr = row0 / p.OH, oh = row0 - fr * p.OH;
+        const size_t pp = ((size_t)fr * (p.OH >> 1) + (oh >> 1)) << pw_sh;     // first pooled pixel: the 8 follow row-major
+        for (int idx = lane; idx < 8 * ROW4; idx += 64) {
+          const int q = idx / ROW4, c4 = idx - q * ROW4;
+          const int n = n0 + wn * TN * 32 + c4 * 4;
+          if (n >= p.Cout) continue;
+          const int pr = q >> pw_sh, pc = q & ((1 << pw_sh) - 1);
+          const float* s0 = sC + ((2 * pr) * p.OW + 2 * pc) * LDC + c4 * 4;
+          const float4 a = *reinterpret_cast<const float4*>(s0);
+          const float4 b = *reinterpret_cast<const float4*>(s0 + LDC);
+          const float4 c = *reinterpret_cast<const float4*>(s0 + p.OW * LDC);
+          const float4 d = *reinterpret_cast<const float4*>(s0 + (p.OW + 1) * LDC);
+          float4 t;
+          t.x = fmaxf(fmaxf(a.x, b.x), fmaxf(c.x, d.x)); t.y = fmaxf(fmaxf(a.y, b.y), fmaxf(c.y, d.y));
+          t.z = fmaxf(fmaxf(a.z, b.z), fmaxf(c.z, d.z)); t.w = fmaxf(fmaxf(a.w, b.w), fmaxf(c.w, d.w));
+          *reinterpret_cast<float4*>(p.y_pool + (pp + q) * p.ldyp + n) = t;
+        }
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // (the split wide tiling stages its second slice into this slab next)
     }
   }
 }

@@ -258,7 +258,7 @@ int launch_cfg(const ConvArgs& a, bool vec4, int epi, hipStream_t s) {
   if (tiles <= 0 || tiles > 0x7fffffffLL) return DH_EINVAL;
   constexpr int kStage = BM * LDA + BK * BN, kEpi = WM * WN * 32 * (TN * 32 + 4);
   const size_t lds = (size_t)(kStage > kEpi ? kStage : kEpi) * sizeof(float);
-  if (a.y_pool != nullptr && !conv_epilogue_pools<WM, TM, false>()) return DH_EUNSUPPORTED;
+  if (a.y_pool != nullptr && !conv_epilogue_pools_for<WM, TM, false>(a)) return DH_EUNSUPPORTED;
   if (a.up2) {
     if (!vec4) return DH_EUNSUPPORTED;
     if constexpr (TM * TN >= 6) return DH_EUNSUPPORTED;  // would spill; the dispatcher never asks for it
@@ -313,8 +313,9 @@ int launch_conv_igemm(const ConvArgs& a, int cfg, hipStream_t s) {
   if (a.x_u8 && a.in_lut == nullptr) return DH_EINVAL;
   // tiny output, long reduction: the in-work-group split-K kernel, whatever tiling was asked for (shape rule: the
   // result bits of a layer must not depend on a timing-based choice)
-  if (a.y_pool != nullptr) {             // pooled second output: the epilogue's pairing needs one image row per wave
-    const bool ok = a.OW == 32 && a.OH % 2 == 0 && !a.up2 && !a.x_u8 && a.ldyp % 4 == 0 && a.Cout % 4 == 0 &&
+  if (a.y_pool != nullptr) {             // pooled second output: one image row per wave (pairs of waves pool), or [r06] two /
+                                         // four whole image rows per wave (OW = 16 / 8: the wave pools alone)
+    const bool ok = (a.OW == 32 || ((a.OW == 16 || a.OW == 8) && (a.OH * a.OW) % 32 == 0)) && a.OH % 2 == 0 && !a.up2 && !a.x_u8 && a.ldyp % 4 == 0 && a.Cout % 4 == 0 &&
                     (reinterpret_cast<uintptr_t>(a.y_pool) & 15) == 0 && a.ldy % 4 == 0 && a.w_split != 2 &&
                     (reinterpret_cast<uintptr_t>(a.y) & 15) == 0 && !conv_is_skinny(a);
     if (!ok) return DH_EUNSUPPORTED;
@@ -337,7 +338,7 @@ int launch_conv_igemm(const ConvArgs& a, int cfg, hipStream_t s) {
   if (a.w_split == 2) return launch_conv_halo(a, cfg, epi_with_direct(a, epi, false), s);   // chunk-major fp32 packing: the halo-resident kernel only
   if (cfg < 0 && a.y_pool != nullptr) {
     cfg = conv_igemm_pick_cfg(a.N * a.OH * a.OW, a.Cout);
-    if (cfg == 8) cfg = 7;                // 32 x 32 has no wave pair
+    if (cfg == 8 && a.OW == 32) cfg = 7;  // 32 x 32 has no wave pair
     if (cfg == 0 || cfg == 1) cfg = 2;    // 64-row waves do not pool
     if (!a.w_split && gemm1x1_eligible(a)) cfg += kNumCfgs;
   }

@@ -347,7 +347,7 @@ int launch_cfg(const ConvArgs& a, int epi, hipStream_t s) {
   const long long tiles = ((M + BM - 1) / BM) * ((a.Cout + BN - 1) / BN);
   if (tiles <= 0 || tiles > 0x7fffffffLL) return DH_EINVAL;
   const unsigned t = (unsigned)tiles;
-  if (a.y_pool != nullptr && !conv_epilogue_pools<WM, TM, false>()) return DH_EUNSUPPORTED;
+  if (a.y_pool != nullptr && !conv_epilogue_pools_for<WM, TM, false>(a)) return DH_EUNSUPPORTED;
   if (a.up2) {
     if constexpr (TM * TN >= 6) {
       return DH_EUNSUPPORTED;

@@ -697,8 +697,11 @@ class Planner:
                 return False
             writers = [q for q in steps for v in q.outs.values() if v is not None and v.buf is x.buf]
             readers = [q for q in steps for v in q.ins.values() if v is not None and v.buf is x.buf]
-            return len(writers) == 1 and readers == [st] and all(v.coff == 0 and v.ld == x.C for v in writers[0].outs.values()
-                                                                if v is not None and v.buf is x.buf)
+            # (the producer must be able to write a channel run of a wider buffer: convolutions do -- ZeroPadding2D, in
+            #  front of the pooling when the joint count is not a multiple of four, writes dense rows)
+            return len(writers) == 1 and readers == [st] and writers[0].kind == 'conv' and \
+                writers[0].outs.get('y') is not None and writers[0].outs['y'].buf is x.buf and \
+                all(v.coff == 0 and v.ld == x.C for v in writers[0].outs.values() if v is not None and v.buf is x.buf)
 
         i = 0
         while i < len(steps):
@@ -1100,11 +1103,15 @@ class Planner:
         # (reception.py:105-116: every hourglass level is used at full AND at half resolution).  Bit-identical.  Neutral
         # while the pool ran beside other work on a second stream (round 2); on ONE stream, where the forward is the sum
         # of its kernels, it is worth 1-2 % on the MPII model.  DEEPHAR_FUSE_POOL=0 switches it off.
+        # [r06] also at 16 and 8 columns (a wave's 32 output rows are two / four whole image rows there: it pools alone) --
+        # one dependent launch less per down-scaling unit of SPNet's pyramids (DEEPHAR_FUSE_POOL_SMALL=0: 32 columns only).
         prod = self.producer.get(id(x))
         if os.environ.get('DEEPHAR_FUSE_POOL', '1') != '0' and prod is not None and prod.kind == 'conv' and \
                 prod.outs.get('y') is x and 'ypool' not in prod.outs and not prod.attrs.get('up2') and \
                 a.get('mode', 0) == 0 and (a['kh'], a['kw'], a['sh'], a['sw'], a['pt'], a['pl']) == (2, 2, 2, 2, 0, 0) and \
-                x.shape[-2] == 32 and x.shape[-3] % 2 == 0 and x.C % 4 == 0 and x.ld % 4 == 0 and y.ld % 4 == 0 and \
+                (x.shape[-2] == 32 or (x.shape[-2] in (8, 16) and (x.shape[-3] * x.shape[-2]) % 32 == 0 and
+                                       os.environ.get('DEEPHAR_FUSE_POOL_SMALL', '1') != '0')) and \
+                x.shape[-3] % 2 == 0 and x.C % 4 == 0 and x.ld % 4 == 0 and y.ld % 4 == 0 and \
                 x.coff % 4 == 0 and y.coff % 4 == 0 and \
                 not (prod.attrs['kh'] * prod.attrs['kw'] > 1 and prod.attrs['Cin'] % 32 == 16) and \
                 not split_k_rule(x.shape[-3] * x.shape[-2], prod.attrs['K'], prod.attrs['Cout'], prod.attrs['Cin'],

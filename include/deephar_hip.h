@@ -97,7 +97,9 @@ typedef struct dh_conv_args {
                     at half resolution (reception.py:105-116: x = ...; MaxPooling2D((2, 2))(x)), and a stand-alone pool
                     has to read the whole tensor back.  Built for OW == 32, OH even, 16-byte aligned rows, no up2, on the
                     tilings whose waves own 32-row blocks in pairs (an image row per wave, the pair pools through the
-                    epilogue's LDS slab); anything else returns DH_EUNSUPPORTED */
+                    epilogue's LDS slab), and [r06] for OW == 16 / OW == 8 with OH * OW a multiple of 32 on every tiling
+                    with 32-row waves (a wave's block is two / four whole image rows: it pools its own slab -- SPNet's
+                    down path below 32 x 32, common.py:70-86); anything else returns DH_EUNSUPPORTED */
 } dh_conv_args;
 
 /* padded dims of the packed weight for a [KH,KW,Cin,Cout] (Keras HWIO) kernel */

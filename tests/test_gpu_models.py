@@ -271,8 +271,9 @@ def test_resample_on_load_rule_is_bit_identical(hip_lib, cuda, monkeypatch):
 def test_sibling_pools_merged_are_bit_identical(hip_lib, cuda, monkeypatch):
     """[r06] Planner rule R13: the action head's two poolings (pose features, appearance features: spnet.py:126-133) read one
     joint buffer their producers fill and run as ONE launch into the concatenation: one launch less per head, not one bit
-    moved -- 2-D replica model and 3-D model, one and two streams, 8-frame clips (window stride (1, 2)) and 16-frame clips
-    (stride (2, 2))."""
+    moved -- 2-D replica model, one and two streams, 8-frame clips (window stride (1, 2)) and 16-frame clips (stride (2, 2));
+    the 17-joint 3-D model zero-pads its features to 20 joints in front of the pooling (spnet.py:124-132): ZeroPadding2D writes
+    dense rows, the rule leaves those heads alone."""
     for frames, seed in ((8, 41), (16, 43)):
         clips = np.random.default_rng(seed).uniform(-1, 1, (2, frames, 128, 128, 3)).astype(np.float32)
         for layout, nact, rep in (('pa16j2d', 15, True), ('pa17j3d', 60, False)):
@@ -285,7 +286,8 @@ def test_sibling_pools_merged_are_bit_identical(hip_lib, cuda, monkeypatch):
                 m, _, _, _ = _spnet(frames, layout, nact, 2, [1, 2], 160, replica=rep, res=128)
                 m.num_streams, m.stream_policy = streams, policy
                 joint = [s for s in m.plan.steps if s.kind == 'pool' and '+' in (s.name or '')]
-                assert len(joint) == 6 and len(m.plan.steps) == nbase - 6, (len(joint), len(m.plan.steps), nbase)
+                want_joint = 6 if layout == 'pa16j2d' else 0
+                assert len(joint) == want_joint and len(m.plan.steps) == nbase - want_joint, (len(joint), len(m.plan.steps), nbase)
                 assert all(s.ins['x'].C == 320 and s.ins['x'].ld == 320 and s.outs['y'].C == 320 for s in joint)
                 for a, b in zip(want, m.predict(clips, batch_size=2)):
                     assert np.array_equal(a, b), (frames, layout, streams)
@@ -782,9 +784,10 @@ def test_pooled_epilogue_plan_is_bit_identical(hip_lib, cuda, monkeypatch):
             m.gemm_precision = mode
             x = np.random.default_rng(3).uniform(-1, 1, (3, 256, 256, 3)).astype(np.float32)
             outs[fuse] = m.predict(x, batch_size=3)
-            n_pool = sum(1 for s in m.plan.steps if s.kind == 'pool' and s.ins['x'].shape[-2] == 32)
+            n_pool = sum(1 for s in m.plan.steps if s.kind == 'pool' and s.ins['x'].shape[-2] in (16, 32))
             n_fused = sum(1 for s in m.plan.steps if s.kind == 'conv' and 'ypool' in s.outs)
-            assert (n_fused, n_pool) == ((3, 0) if fuse == '1' else (0, 3)), (mode, fuse, n_fused, n_pool)
+            # three hourglasses x (32-column pool + [r06] the 16-column pool behind it)
+            assert (n_fused, n_pool) == ((6, 0) if fuse == '1' else (0, 6)), (mode, fuse, n_fused, n_pool)
         monkeypatch.delenv('DEEPHAR_FUSE_POOL')
         for a, b in zip(outs['1'], outs['0']):
             assert np.array_equal(a, b), mode

@@ -832,8 +832,53 @@ def test_conv2d_pooled_second_output(case, hip_lib, cuda):
     assert (False, 8) not in took and (False, 17) not in took and (False, 0) not in took      # no wave pair / 64-row waves
     if cin % 32 == 0 or ks == 1:
         assert (True, 14) in took and (True, 2) in took
-    with pytest.raises(Exception):                                                          # 16 columns: not built
-        F.conv2d(d(np.ascontiguousarray(x[:, :, :16 * st])), k, pool2=True, **dict(kw, res1=None))
+    with pytest.raises(Exception):                                                          # 12 columns: not built
+        F.conv2d(d(np.ascontiguousarray(x[:, :, :12 * st])), k, pool2=True, **dict(kw, res1=None))
+
+
+@pytest.mark.parametrize('case', [(3, 16, 16, 32, 384, 1, True, True, True), (2, 8, 8, 480, 480, 1, False, False, False),
+                                  (2, 16, 16, 96, 320, 3, True, True, False), (5, 8, 8, 64, 300, 1, True, True, False),
+                                  (1, 4, 8, 288, 288, 1, False, True, False), (2, 32, 16, 64, 96, 3, False, True, True)])
+def test_conv2d_pooled_second_output_small_maps(case, hip_lib, cuda):
+    """[r06] dh_conv_args.y_pool at OW = 16 / OW = 8 (OH * OW a multiple of 32): a wave's 32 output rows are two / four whole
+    image rows and the wave pools its own slab -- every tiling with 32-row waves takes it, incl. the one-wave 32 x 32 tiling
+    the latency regime runs (SPNet's down path below 32 x 32: common.py:70-86 after the prediction block's conv2 with its two
+    residuals).  Equal to the stand-alone pooling of the first output, which is unchanged; fp32 and split-bf16."""
+    from deephar_amd import functional as F
+    n, h, w, cin, cout, ks, relu, res, res2 = case
+    rng = np.random.default_rng(7 + sum(int(v) for v in case))
+    x = _rand(rng, (n, h, w, cin))
+    k = _rand(rng, (ks, ks, cin, cout), np.sqrt(1.0 / (ks * ks * cin)))
+    sc = rng.uniform(0.5, 1.5, cout).astype(np.float32)
+    sh = _rand(rng, (cout,), 0.1)
+    d = lambda a: None if a is None else torch.from_numpy(a).to(cuda)
+    r1 = _rand(rng, (n, h, w, cout)) if res else None
+    r2 = _rand(rng, (n, h, w, cout)) if res2 else None
+    kw = dict(padding='same', pre_relu=relu, post_scale=d(sc), post_shift=d(sh), res1=d(r1), res2=d(r2), post_relu=not res2)
+    base = F.conv2d(d(x), k, **kw)
+    ref_pool = F.pool2d(base, (2, 2))
+    took = {}
+    for split in (False, True):
+        ncfg = hip_lib.dh_conv2d_num_split_tile_cfgs() if split else hip_lib.dh_conv2d_num_tile_cfgs()
+        ref_y = F.conv2d(d(x), k, split=split, **kw)
+        for cfg in range(-1, ncfg):
+            try:
+                y, yp = F.conv2d(d(x), k, split=split, tile_cfg=cfg, pool2=True, **kw)
+            except Exception as e:
+                assert 'rc=-2' in str(e), e
+                continue
+            took[(split, cfg)] = True
+            assert yp.shape == (n, h // 2, w // 2, cout)
+            assert torch.equal(y, ref_y), (split, cfg)
+            assert torch.equal(yp, F.pool2d(y, (2, 2))), (split, cfg)
+            if not split:
+                assert torch.equal(yp, ref_pool)
+    # the library's own pick, the one-wave tiling (no partner needed here) and the paired ones; 64-row waves still refuse
+    assert (False, -1) in took and (False, 8) in took and (False, 2) in took and (False, 0) not in took
+    if ks == 1:
+        assert (False, 17) in took and (False, 13) in took
+    if cin % 32 == 0 or ks == 1:
+        assert (True, -1) in took
 
 
 SKINNY_CASES = [

@@ -119,7 +119,9 @@ def test_planner_fusion_rules():
     kinds = [s.kind for s in plan.steps]
     # nothing but kernels that exist; BN / ReLU / add / concat / upsample never survive as their own launch
     assert set(kinds) <= {'conv', 'dwconv', 'pool', 'sam_ctx'}
-    assert sum(1 for s in plan.steps if s.kind == 'conv' and 'ypool' in s.outs) == 2          # R7: one per block
+    # R7: the two poolings of every hourglass (reception.py:105-116) are second outputs of the convolutions in front of them
+    # -- at 32 columns (pairs of waves pool) and, [r06], at 16 columns (a wave pools its two image rows alone)
+    assert sorted(s.outs['y'].shape[-2] for s in plan.steps if s.kind == 'conv' and 'ypool' in s.outs) == [16, 16, 32, 32]
     convs = [s for s in plan.steps if s.kind == 'conv']
     # R3: both add([a, UpSampling2D(b)]) of every hourglass are second residuals, read at half resolution, of the
     # convolutions that produce `a`; those are emitted after the low-resolution branch that produces `b`
@@ -169,7 +171,10 @@ def test_planner_wide_adds_become_conv_epilogues(monkeypatch):
     plan = m1.plan
     assert base.split_adds is False and plan.split_adds is True      # read once per plan, recorded in it
     adds = lambda p: [s for s in p.steps if s.kind == 'eltwise' and s.attrs.get('op', 0) == 0 and 'b' in s.ins]
-    assert len(adds(base)) == 15 and len(adds(plan)) == 0 and len(plan.steps) == len(base.steps) - 15
+    # (a sum that became a convolution's epilogue can also carry the pooling behind it: rule R7 -- those launches go too)
+    npool = lambda p: sum(1 for s in p.steps if s.kind == 'conv' and 'ypool' in s.outs)
+    assert len(adds(base)) == 15 and len(adds(plan)) == 0
+    assert len(plan.steps) == len(base.steps) - 15 - (npool(plan) - npool(base))
     assert sum(1 for n in m1._nodes if n.op == 'add' and len(n.inputs) == 4) == 5          # the graph itself keeps its adds (the last block re-injects nothing)
     assert abs(sum(s.flops() for s in plan.steps) - sum(s.flops() for s in base.steps)) < 1.0
     assert sum(s.bytes() for s in plan.steps) < sum(s.bytes() for s in base.steps)
@@ -273,18 +278,23 @@ def test_tail_stream_policy_is_one_directional_and_sound():
 
 
 def test_planner_pooled_output_rule(monkeypatch):
-    """R7: the 32-column MaxPooling2D becomes a second output of the convolution that feeds it; same algorithmic FLOPs,
-    one launch and one full-resolution read less per block, and the memory plan stays sound (DEEPHAR_FUSE_POOL=0: off)."""
+    """R7: the 32-column MaxPooling2D -- [r06] and the 16-column one behind it -- becomes a second output of the convolution
+    that feeds it; same algorithmic FLOPs, a launch and a full-resolution read less each, and the memory plan stays sound
+    (DEEPHAR_FUSE_POOL=0: off; DEEPHAR_FUSE_POOL_SMALL=0: 32 columns only)."""
     monkeypatch.setenv('DEEPHAR_FUSE_POOL', '0')
     base = _mpii(2).plan
     monkeypatch.setenv('DEEPHAR_FUSE_POOL', '1')
     plan = _mpii(2).plan
     fused = [s for s in plan.steps if s.kind == 'conv' and 'ypool' in s.outs]
-    assert len(fused) == 2 and len(plan.steps) == len(base.steps) - 2
+    assert len(fused) == 4 and len(plan.steps) == len(base.steps) - 4
     for s in fused:
         y, yp = s.outs['y'], s.outs['ypool']
-        assert y.shape[-2] == 32 and yp.shape[-3:] == (y.shape[-3] // 2, 16, y.C) and s.attrs['pool2'] == 1
-    assert not any(s.kind == 'pool' and s.ins['x'].shape[-2] == 32 for s in plan.steps)
+        assert y.shape[-2] in (16, 32) and yp.shape[-3:] == (y.shape[-3] // 2, y.shape[-2] // 2, y.C) and s.attrs['pool2'] == 1
+    assert not any(s.kind == 'pool' and s.ins['x'].shape[-2] in (16, 32) for s in plan.steps)
+    monkeypatch.setenv('DEEPHAR_FUSE_POOL_SMALL', '0')
+    wide_only = _mpii(2).plan
+    assert [s.outs['y'].shape[-2] for s in wide_only.steps if s.kind == 'conv' and 'ypool' in s.outs] == [32, 32]
+    monkeypatch.delenv('DEEPHAR_FUSE_POOL_SMALL')
     assert sum(s.flops() for s in plan.steps) == sum(s.flops() for s in base.steps)
     assert sum(s.bytes() for s in plan.steps) < sum(s.bytes() for s in base.steps)
     for i, s in enumerate(plan.steps):
@@ -616,15 +626,15 @@ def test_round6_planner_rules_on_the_host(monkeypatch):
 
     def plan(**env):
         for k in ('DEEPHAR_MERGE_KXK', 'DEEPHAR_MERGE_SIBLINGS', 'DEEPHAR_UP_COMMUTE', 'DEEPHAR_RESAMPLE_ON_LOAD', 'DEEPHAR_FOLD_POSE_MUL',
-                  'DEEPHAR_MERGE_POOLS'):
+                  'DEEPHAR_MERGE_POOLS', 'DEEPHAR_FUSE_POOL_SMALL'):
             monkeypatch.setenv(k, env.get(k, '1'))
         full = bench.build_speed2d()
         m = Model(full.input, full.outputs[34:36])
         return m, m.plan
     _, off = plan(DEEPHAR_MERGE_KXK='0', DEEPHAR_MERGE_SIBLINGS='0', DEEPHAR_UP_COMMUTE='0', DEEPHAR_RESAMPLE_ON_LOAD='0',
-                  DEEPHAR_FOLD_POSE_MUL='0', DEEPHAR_MERGE_POOLS='0')
+                  DEEPHAR_FOLD_POSE_MUL='0', DEEPHAR_MERGE_POOLS='0', DEEPHAR_FUSE_POOL_SMALL='0')
     m, on = plan()
-    assert len(off.steps) == 604 and len(on.steps) == 437
+    assert len(off.steps) == 604 and len(on.steps) == 431
     # R10b: eighteen action heads, each opens with ONE 3x5 convolution of 70 columns whose parts sit centred in the window
     kxk = [s for s in on.steps if s.kind == 'conv' and (s.name or '').count('p_conv0') == 3]
     assert len(kxk) == 18 and all((s.attrs['kh'], s.attrs['kw'], s.attrs['pt'], s.attrs['pl'], s.attrs['Cout'], s.attrs['K']) ==
@@ -669,6 +679,10 @@ def test_round6_planner_rules_on_the_host(monkeypatch):
         writers = [q for q in on.steps for v in q.outs.values() if v is not None and v.buf is s.ins['x'].buf]
         assert sorted((v.coff, v.C) for q in writers for v in q.outs.values() if v.buf is s.ins['x'].buf) == [(0, 160), (160, 160)]
         assert all(on.steps.index(q) < on.steps.index(s) for q in writers)
+    # R7 at 16 / 8 columns: the down-scaling units' MaxPooling2D is the second output of the prediction block's conv2
+    pooled = [s for s in on.steps if s.kind == 'conv' and 'ypool' in s.outs]
+    assert sorted(s.outs['y'].shape[-2] for s in pooled) == [8] * 3 + [16] * 3 + [32] * 2 and \
+        all(s.outs['ypool'].shape[-2] * 2 == s.outs['y'].shape[-2] for s in pooled)
     # the arithmetic that is left: the up-scaling shortcuts run on a quarter of the pixels, nothing else changed
     assert sum(s.flops() for s in on.steps) < sum(s.flops() for s in off.steps)
 
