@@ -283,6 +283,12 @@ def epilogue_tag(s):
     return '+'.join(parts) or 'plain'
 
 
+def real_launches(bound):
+    """Kernel launches of one forward: the plan's steps minus those a grouped / paired launch absorbed
+    (BoundPlan.group_launches: dh_conv2d_dw_group_f32, dh_conv2d_pair_f32)."""
+    return sum(len(bp.calls) - len(bp.noop_calls) for bp, _ in bound)
+
+
 def profile_plans(bound):
     """bound: [(BoundPlan, stream_ptr)].  Per-step HIP-event times of an eager pass -> (rows, kinds)."""
     rows, kinds = [], {}
@@ -426,7 +432,8 @@ def speed2d_protocol(full_model, args, tune_table):
         out = m.predict(x, batch_size=2)
         warm.append(round(clips * T / (time.perf_counter() - t0), 1))
         assert len(out) == 2 and len(out[0]) == clips and all(np.all(np.isfinite(o)) for o in out)
-        launches.append(len(m.plan.steps))
+        bp2 = m.executor.bound.get(2)
+        launches.append(len(bp2.calls) - len(bp2.noop_calls) if bp2 is not None else len(m.plan.steps))
         gflop.append(round(m.plan.total_flops(2) / 1e9, 2))
         del m
     return {'protocol': 'exp/pennaction/eval_speed2d.py:55-79', 'num_clips': clips, 'num_frames': T, 'batch_size': 2,
@@ -563,7 +570,7 @@ def compact_leg(workload, args, rank):
             'main_shape_mkn', 'main_shape_epilogue', 'main_shape_avg_launch_us', 'main_shape_launches_per_step',
             'algorithmic_bytes_per_launch', 'share_of_step_time')
     leg = {'workload': wl['name'], 'value': round(frames * steps / dt, 1), 'unit': 'frames/s', 'steps': steps,
-           'ms_per_step': round(ms, 3), 'frames_per_step': frames, 'launches_per_step': len(rows),
+           'ms_per_step': round(ms, 3), 'frames_per_step': frames, 'launches_per_step': real_launches(bound), 'plan_steps': len(rows),
            'streams': model.plan.nstreams if not wl['clips'] else 1,
            'whole_forward_frac': roof['whole_forward_frac'], 'gflop_per_step': round(flops / 1e9, 1),
            'outputs_finite_in_range': bool(np.all(np.isfinite(pose)) and pose[..., :2].min() >= 0 and pose[..., :2].max() <= 1),
@@ -919,6 +926,8 @@ def main():
     rows, kinds = profile_plans(bound)
     ms_per_step = 1e3 * dt / args.steps
     roof, extra = roofline(rows, kinds, flops_per_step, ms_per_step)
+    roof['launches_per_forward'] = real_launches(bound)      # (plan steps minus those absorbed by grouped / paired launches)
+    roof['plan_steps'] = len(rows)
 
     # The default line also measures the opt-in split-bf16 GEMM mode (Model.gemm_precision = 'bf16x3'): same model, same
     # batch, same timing; reported under "bf16x3", never as `value` (the headline stays on the fp32-MFMA path).

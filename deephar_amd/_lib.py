@@ -64,6 +64,7 @@ SIGNATURES = {
     'dh_normalize_u8_f32': (C.c_int, [vp, vp, vp, C.c_int64, C.c_int, vp]),
     'dh_dwconv2d_f32': (C.c_int, [C.POINTER(DwArgs), vp]),
     'dh_conv2d_dw_group_f32': (C.c_int, [C.POINTER(ConvArgs), C.POINTER(DwArgs), vp]),
+    'dh_conv2d_pair_f32': (C.c_int, [C.POINTER(ConvArgs), C.POINTER(ConvArgs), vp]),
     'dh_pool2d_f32': (C.c_int, [C.POINTER(PoolArgs), vp]),
     'dh_upsample2x_add_f32': (C.c_int, [vp, C.c_int, vp, C.c_int, vp, C.c_int] + [C.c_int] * 4 + [vp]),
     'dh_eltwise_f32': (C.c_int, [C.POINTER(EltArgs), vp]),

@@ -130,6 +130,18 @@ int dh_conv2d_dw_group_f32(const dh_conv_args* a, const dh_dw_args* d, void* str
   return launch_conv_dw_group(*a, *d, S(stream));
 }
 
+int dh_conv2d_pair_f32(const dh_conv_args* a, const dh_conv_args* b, void* stream) {
+  for (const dh_conv_args* c : {a, b}) {
+    if (c == nullptr || c->x == nullptr || c->w == nullptr || c->y == nullptr) return DH_EINVAL;
+    if ((c->pre_scale == nullptr) != (c->pre_shift == nullptr) || (c->post_scale == nullptr) != (c->post_shift == nullptr)) return DH_EINVAL;
+    if (c->SH <= 0 || c->SW <= 0 || c->KH <= 0 || c->KW <= 0 || c->N <= 0 || c->Cin <= 0 || c->Cout <= 0 || c->OH <= 0 || c->OW <= 0)
+      return DH_EINVAL;
+    if (c->Kp % 32 != 0 || c->Np % 32 != 0 || c->Kp < c->K || c->Np < c->Cout || c->K != c->KH * c->KW * c->Cin) return DH_EINVAL;
+    if ((long long)c->N * c->H * c->W > 0x7fffffffLL || (long long)c->N * c->OH * c->OW * (c->up2 ? 4 : 1) > 0x7fffffffLL) return DH_EINVAL;
+  }
+  return launch_conv_skinny_pair(*a, *b, S(stream));
+}
+
 int dh_normalize_u8_f32(const uint8_t* x, const float* lut, float* y, int64_t n_pixels, int C, void* stream) {
   if (x == nullptr || lut == nullptr || y == nullptr) return DH_EINVAL;
   return launch_normalize_u8(x, lut, y, n_pixels, C, S(stream));

@@ -33,18 +33,22 @@ constexpr int SK_MAX_CIN = 4096; // prologue table in LDS: 2 x Cin floats
 // (input pixel (h, w) = x(h / 2, w / 2)); 2 / 3 = x is stored at DOUBLE resolution and read through MaxPooling2D((2, 2)) /
 // layers.max_min_pooling((2, 2)) (max, or max + min, of the four pixels) -- the prologue and the zero padding act on the
 // resampled pixels, exactly as if the up-sampling / pooling launch had written them out.
+// `block`: the tile index (blockIdx.x, or the index inside one convolution's range of a paired launch).  A work-group that
+// was launched with more than NWV waves (the pair's other convolution needs them) retires the extra ones here: a wave that
+// has ended no longer counts at s_barrier.
 template <int NWV, bool VEC, int RS>
-__global__ __launch_bounds__(NWV * 64) void conv_skinny_kernel(const ConvArgs p, const unsigned magic_cin, const unsigned magic_kw) {
-  extern __shared__ __attribute__((aligned(16))) float sk_lds[];
+__device__ __forceinline__ void conv_skinny_body(const ConvArgs& p, const unsigned magic_cin, const unsigned magic_kw, float* sk_lds,
+                                                 const int block) {
   float (*red)[4][64] = reinterpret_cast<float (*)[4][64]>(sk_lds);            // [NWV][4][64] partial tiles
   float* pre_tab = sk_lds + NWV * 4 * 64;                                        // [2][Cin4]: scale, shift (BN prologue only)
   const int tid = threadIdx.x;
+  if (tid >= NWV * 64) return;
   const int lane = tid & 63, wave = tid >> 6;
   const int li = lane & 15, lg = lane >> 4;               // v_mfma_f32_16x16x4_f32: A[row li][k lg], B[k lg][col li]
   const int M = p.N * p.OH * p.OW;
   const int tiles_n = (p.Cout + 15) / 16;
-  const int m0 = (blockIdx.x / tiles_n) * 16;
-  const int n0 = (blockIdx.x % tiles_n) * 16;
+  const int m0 = (block / tiles_n) * 16;
+  const int n0 = (block % tiles_n) * 16;
   const bool aff = p.pre_scale != nullptr;
   const int cin4 = (p.Cin + 3) & ~3;
   constexpr int SK_DEPTH = RS >= 2 ? (VEC ? 4 : 2) : (VEC ? 8 : 4);   // k-group quads in flight per wave (dword form: 4 loads per quad and
@@ -220,6 +224,39 @@ __global__ __launch_bounds__(NWV * 64) void conv_skinny_kernel(const ConvArgs p,
   }
 }
 
+template <int NWV, bool VEC, int RS>
+__global__ __launch_bounds__(NWV * 64) void conv_skinny_kernel(const ConvArgs p, const unsigned magic_cin, const unsigned magic_kw) {
+  extern __shared__ __attribute__((aligned(16))) float sk_lds[];
+  conv_skinny_body<NWV, VEC, RS>(p, magic_cin, magic_kw, sk_lds, (int)blockIdx.x);
+}
+
+// [r06] Two INDEPENDENT skinny convolutions in one launch (dh_conv2d_pair_f32): work-groups [0, tiles_a) run the first,
+// the rest the second, each with the code of its own instantiation (wave count from its K, vector / scalar loads) -- the
+// bits of either are those of its own launch.  `code` = 2 * log2(NWV / 4) + VEC.  Plain inputs only (x_resample = 0).
+template <int NMAX>
+__device__ __forceinline__ void conv_skinny_dispatch(const ConvArgs& p, const int code, const unsigned magic_cin, const unsigned magic_kw,
+                                                     float* lds, const int block) {
+  switch (code) {
+    case 0: conv_skinny_body<4, false, 0>(p, magic_cin, magic_kw, lds, block); break;
+    case 1: conv_skinny_body<4, true, 0>(p, magic_cin, magic_kw, lds, block); break;
+    case 2: if constexpr (NMAX >= 8) conv_skinny_body<8, false, 0>(p, magic_cin, magic_kw, lds, block); break;
+    case 3: if constexpr (NMAX >= 8) conv_skinny_body<8, true, 0>(p, magic_cin, magic_kw, lds, block); break;
+    case 4: if constexpr (NMAX >= 16) conv_skinny_body<16, false, 0>(p, magic_cin, magic_kw, lds, block); break;
+    case 5: if constexpr (NMAX >= 16) conv_skinny_body<16, true, 0>(p, magic_cin, magic_kw, lds, block); break;
+  }
+}
+
+template <int NMAX>
+__global__ __launch_bounds__(NMAX * 64) void conv_skinny_pair_kernel(const ConvArgs pa, const ConvArgs pb, const int tiles_a, const int code_a,
+                                                                      const int code_b, const unsigned magic_cin_a, const unsigned magic_kw_a,
+                                                                      const unsigned magic_cin_b, const unsigned magic_kw_b) {
+  extern __shared__ __attribute__((aligned(16))) float sk_lds[];
+  if ((int)blockIdx.x < tiles_a)
+    conv_skinny_dispatch<NMAX>(pa, code_a, magic_cin_a, magic_kw_a, sk_lds, (int)blockIdx.x);
+  else
+    conv_skinny_dispatch<NMAX>(pb, code_b, magic_cin_b, magic_kw_b, sk_lds, (int)blockIdx.x - tiles_a);
+}
+
 template <int NWV, int RS>
 int launch_skinny_rs(const ConvArgs& a, unsigned tiles, bool vec, hipStream_t s) {
   const unsigned magic_cin = (unsigned)((1ull << 32) / (unsigned)a.Cin + 1ull);       // k / Cin = umulhi(k, magic), k * Cin < 2^32
@@ -269,6 +306,46 @@ bool conv_is_skinny(const ConvArgs& a) {
 int conv_skinny_waves(int Kp) {
   const int quads = Kp / 16;
   return quads > 32 ? 16 : (quads > 8 ? 8 : 4);
+}
+
+namespace {
+struct SkinnyLaunch { long long tiles; int nwv; bool vec; unsigned magic_cin, magic_kw; size_t lds; };
+int skinny_launch_shape(const ConvArgs& a, SkinnyLaunch* o) {
+  const long long M = (long long)a.N * a.OH * a.OW;
+  o->tiles = ((M + 15) / 16) * ((a.Cout + 15) / 16);
+  if (o->tiles <= 0 || o->tiles > 0x3fffffffLL || (long long)a.H * a.W * a.ldx > 0x7fffffffLL || a.Kp % 16 != 0) return DH_EINVAL;
+  auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
+  o->vec = a.Cin % 4 == 0 && a.ldx % 4 == 0 && al16(a.x);
+  o->nwv = conv_skinny_waves(a.Kp);
+  o->magic_cin = (unsigned)((1ull << 32) / (unsigned)a.Cin + 1ull);
+  o->magic_kw = (1u << 16) / (unsigned)a.KW + 1u;
+  o->lds = ((size_t)o->nwv * 4 * 64 + (a.pre_scale != nullptr ? (size_t)2 * ((a.Cin + 3) & ~3) : 0)) * sizeof(float);
+  return DH_OK;
+}
+template <int NMAX>
+int launch_pair(const ConvArgs& a, const ConvArgs& b, const SkinnyLaunch& la, const SkinnyLaunch& lb, hipStream_t s) {
+  auto code = [](const SkinnyLaunch& l) { return 2 * (l.nwv == 16 ? 2 : (l.nwv == 8 ? 1 : 0)) + (l.vec ? 1 : 0); };
+  const size_t lds = la.lds > lb.lds ? la.lds : lb.lds;
+  hipLaunchKernelGGL((conv_skinny_pair_kernel<NMAX>), dim3((unsigned)(la.tiles + lb.tiles)), dim3(NMAX * 64), lds, s, a, b, (int)la.tiles,
+                     code(la), code(lb), la.magic_cin, la.magic_kw, lb.magic_cin, lb.magic_kw);
+  return check_launch();
+}
+}  // namespace
+
+// dh_conv2d_pair_f32: both convolutions on the skinny-conv kernel (conv_is_skinny), inputs as stored (x_resample = 0), no
+// second residual at half resolution -- anything else is for the two entry points.
+int launch_conv_skinny_pair(const ConvArgs& a, const ConvArgs& b, hipStream_t s) {
+  if (!conv_is_skinny(a) || !conv_is_skinny(b) || a.x_resample || b.x_resample || a.res2_down || b.res2_down || a.y_pool != nullptr ||
+      b.y_pool != nullptr)
+    return DH_EUNSUPPORTED;
+  SkinnyLaunch la, lb;
+  if (skinny_launch_shape(a, &la) != DH_OK || skinny_launch_shape(b, &lb) != DH_OK) return DH_EINVAL;
+  const int nmax = la.nwv > lb.nwv ? la.nwv : lb.nwv;
+  switch (nmax) {
+    case 16: return launch_pair<16>(a, b, la, lb, s);
+    case 8: return launch_pair<8>(a, b, la, lb, s);
+    default: return launch_pair<4>(a, b, la, lb, s);
+  }
 }
 
 int launch_conv_splitk(const ConvArgs& a, hipStream_t s) {

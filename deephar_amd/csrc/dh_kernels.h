@@ -25,6 +25,7 @@ bool conv_halo_eligible(const ConvArgs& a);
 int conv_halo_num_cfgs();
 int launch_dwconv(const DwArgs& a, hipStream_t s);
 int launch_conv_dw_group(const ConvArgs& a, const DwArgs& d, hipStream_t s);
+int launch_conv_skinny_pair(const ConvArgs& a, const ConvArgs& b, hipStream_t s);
 int launch_pool(const PoolArgs& a, hipStream_t s);
 int launch_upsample2x_add(const float* a, int lda, const float* b, int ldb, float* y, int ldy, int N, int H,
                           int W, int C, hipStream_t s);

@@ -197,6 +197,8 @@ class BoundPlan:
             self._bind(step)
         self.grouped = 0      # pairs of launches merged into one (group_launches: latency regime only)
         self.noop_calls = set()   # indices of `calls` whose work moved into an earlier, grouped launch
+        self.paired = []          # (index of the paired launch, index of the launch it absorbed): _pair_skinny_convs
+        self.absorbed = {}        # index of a grouped / paired launch -> the Step whose work it also does
 
     def weight_layout(self, args):
         """dh_conv_args.w_split of a conv step: 1 = split-bf16 (plan.gemm_precision == 'bf16x3' and the library takes the
@@ -490,7 +492,7 @@ class BoundPlan:
         rather than by its work into ONE launch (dh_conv2d_dw_group_f32: bit-identical, the work-groups of one grid run
         either kernel's code).  The depthwise entry of `calls` stays as a no-op so that step indices (event waits, per-step
         profiles) keep their meaning.  DEEPHAR_GROUP_LAUNCHES=0 switches it off.  Returns the number of pairs merged."""
-        if os.environ.get('DEEPHAR_GROUP_LAUNCHES', '1') == '0' or self.grouped:
+        if os.environ.get('DEEPHAR_GROUP_LAUNCHES', '1') == '0' or self.grouped or self.paired:
             return self.grouped
         lib = self.lib
         for i in range(self.npre, len(self.calls) - 1):
@@ -516,14 +518,86 @@ class BoundPlan:
             self.calls[i] = (lib.dh_conv2d_dw_group_f32, (ac[0], ad[0]), sc)      # batch size it is bound to -- what counts
             self.calls[j] = (_noop_launch, (), sd)                                 # for execution is `calls` / `noop_calls`)
             self.noop_calls.add(j)
+            self.absorbed[i] = sd
             self.grouped += 1
-        if self.grouped and self.graph is not None:
+        self._pair_skinny_convs(stream_ptr)
+        if (self.grouped or self.paired) and self.graph is not None:
             if self.plan.nstreams > 1:
                 _GRAPH_GRAVEYARD.append(self.graph)
             else:
                 lib.dh_graph_destroy(self.graph)
             self.graph = None
         return self.grouped
+
+    PAIR_LOOKAHEAD = 3              # launches of the same stream a partner may be pulled forward past
+
+    @staticmethod
+    def _values_overlap(v, w):
+        """May the two views touch the same floats?  Same buffer: unless they are disjoint channel runs of one pitch;
+        different buffers: if their arena ranges meet (the memory plan re-uses space)."""
+        if v is None or w is None:
+            return False
+        if v.buf is w.buf:
+            return not (v.ld == w.ld and (v.coff + v.C <= w.coff or w.coff + w.C <= v.coff))
+        a, b = v.buf, w.buf
+        return not (a.offset + a.items <= b.offset or b.offset + b.items <= a.offset)
+
+    @classmethod
+    def _independent(cls, s, t):
+        """neither step reads or overwrites what the other writes"""
+        for o in s.outs.values():
+            if any(cls._values_overlap(o, v) for v in list(t.ins.values()) + list(t.outs.values())):
+                return False
+        for o in t.outs.values():
+            if any(cls._values_overlap(o, v) for v in s.ins.values()):
+                return False
+        return True
+
+    def _pair_skinny_convs(self, stream_ptr):
+        """[r06] Two independent convolutions of the skinny-conv kernel that follow each other on one stream -- the residual unit
+        on the action head's pose features beside `v_conv0` on its appearance features (spnet.py:113-133), the pointwise half of
+        the separable unit on the previous head's features beside this head's conv2 -- become ONE launch (dh_conv2d_pair_f32:
+        work-groups of one grid run either convolution's own code: bit-identical).  The partner is the next launch of the same
+        stream, or one up to PAIR_LOOKAHEAD launches further down that is independent of everything it is pulled past; it must
+        wait for no event itself and pass no launch that does (an event a launch waits for may be the one that orders the
+        partner's inputs too).  DEEPHAR_PAIR_CONVS=0 switches it off."""
+        if os.environ.get('DEEPHAR_PAIR_CONVS', '1') == '0':
+            return
+        lib = self.lib
+
+        def skinny(k):
+            fn, args, st = self.calls[k]
+            if fn is not lib.dh_conv2d_f32 or k in self.noop_calls or st.kind != 'conv':
+                return False
+            ca = args[0]._obj                          # (the latency regime only, like the conv + depthwise groups)
+            return not ca.x_resample and ca.N * ca.OH * ca.OW <= self.GROUP_MAX_ROWS and lib.dh_conv2d_uses_split_k(args[0]) == 1
+
+        i = self.npre
+        while i < len(self.calls) - 1:
+            if not skinny(i):
+                i += 1
+                continue
+            fa, aa, sa = self.calls[i]
+            passed, npassed = [], 0
+            for k in range(i + 1, len(self.calls)):
+                fk, ak, sk = self.calls[k]
+                if sk.stream != sa.stream or k in self.noop_calls:
+                    continue                           # (a no-op's work runs where its group / pair is: see `absorbed` below)
+                if sk.wait or npassed > self.PAIR_LOOKAHEAD:
+                    break
+                if skinny(k) and self._independent(sa, sk) and all(self._independent(q, sk) for q in passed) and \
+                        lib.dh_conv2d_pair_f32(aa[0], ak[0], stream_ptr) == 0:
+                    self.calls[i] = (lib.dh_conv2d_pair_f32, (aa[0], ak[0]), sa)
+                    self.calls[k] = (_noop_launch, (), sk)
+                    self.noop_calls.add(k)
+                    self.absorbed[i] = sk
+                    self.paired.append((i, k))
+                    break
+                passed.append(sk)
+                npassed += 1
+                if k in self.absorbed:                 # a grouped / paired launch does a second step's work at this place
+                    passed.append(self.absorbed[k])
+            i += 1
 
     def capture(self, stream_ptr):
         """Capture the launch sequence into a hipGraph.  -> False (nothing captured; the caller launches eagerly) when

@@ -185,6 +185,14 @@ int dh_dwconv2d_f32(const dh_dw_args* a, void* stream);
  * (exp/pennaction/eval_speed2d.py).  DH_EUNSUPPORTED for any pair outside that description (call the two entry points). */
 int dh_conv2d_dw_group_f32(const dh_conv_args* conv, const dh_dw_args* dw, void* stream);
 
+/* [r06] Two INDEPENDENT convolutions with a tiny output map in ONE launch -- in SPNet's action head (deephar/models/spnet.py:
+ * 113-133) the residual unit on the pose features and `conv2d(af, num_visual_features, (1, 1))` on the appearance features
+ * meet only at the concatenation behind them.  Both must be layers of the skinny-conv kernel (dh_conv2d_uses_split_k), read
+ * their inputs as stored (x_resample = 0) and neither may read or overwrite what the other writes (the caller's business:
+ * they run concurrently).  Work-groups [0, tiles of a) run `a`, the rest `b`, each with the code its own launch would run:
+ * the results are bit for bit those of two dh_conv2d_f32 calls.  DH_EUNSUPPORTED for any other pair. */
+int dh_conv2d_pair_f32(const dh_conv_args* a, const dh_conv_args* b, void* stream);
+
 /* MaxPooling2D (reception.py:74,86,108,115; layers.py:92-97), padding cells ignored;
  * mode 1 = layers.max_min_pooling (layers.py:411-425): maxpool(x) - maxpool(-x) */
 typedef struct dh_pool_args {

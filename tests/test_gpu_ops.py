@@ -336,6 +336,74 @@ def test_conv_dw_grouped_launch(case, hip_lib, cuda):
     assert bool((yc == 7.0).all())
 
 
+def _skinny_args(rng, cuda, n, h, w, cin, cout, ks, bn, relu, res, keep):
+    """(filled dh_conv_args on NaN-initialised output, expected output from dh_conv2d_f32 on the same operands)"""
+    from deephar_amd import functional as F, _lib
+    from deephar_amd.layers import same_pad
+    x = _rand(rng, (n, h, w, cin))
+    k = _rand(rng, (ks, ks, cin, cout), np.sqrt(1.0 / (ks * ks * cin)))
+    d = lambda a_: None if a_ is None else torch.from_numpy(a_).to(cuda)
+    ps, pb = (d(rng.uniform(0.5, 1.5, cin).astype(np.float32)), d(_rand(rng, (cin,), 0.3))) if bn else (None, None)
+    qs, qb = d(rng.uniform(0.5, 1.5, cout).astype(np.float32)), d(_rand(rng, (cout,), 0.3))
+    r1 = d(_rand(rng, (n, h, w, cout))) if res else None
+    xd = d(x)
+    want = F.conv2d(xd, k, pre_scale=ps, pre_shift=pb, pre_relu=relu, post_scale=qs, post_shift=qb, res1=r1, post_relu=not res)
+    wt, kp, np_ = F.pack_conv_weight(k, cuda)
+    y = torch.full_like(want, float('nan'))
+    keep += [xd, wt, ps, pb, qs, qb, r1, y]
+    ptr = lambda t_: t_.data_ptr() if t_ is not None else None
+    a = _lib.ConvArgs()
+    a.x, a.w, a.y, a.pre_scale, a.pre_shift = xd.data_ptr(), wt.data_ptr(), y.data_ptr(), ptr(ps), ptr(pb)
+    a.post_scale, a.post_shift, a.res1 = qs.data_ptr(), qb.data_ptr(), ptr(r1)
+    a.N, a.H, a.W, a.Cin, a.ldx, a.OH, a.OW, a.Cout, a.ldy = n, h, w, cin, cin, h, w, cout, cout
+    a.KH = a.KW = ks
+    a.SH = a.SW = 1
+    a.PT, a.PL = same_pad(h, ks, 1)[0], same_pad(w, ks, 1)[0]
+    a.K, a.Kp, a.Np, a.ldr1, a.pre_relu, a.post_relu = ks * ks * cin, kp, np_, cout, int(relu), int(not res)
+    return a, y, want
+
+
+@pytest.mark.parametrize('case', [
+    # (n, h, w, cin, cout, k, bn prologue, relu, residual) x 2: the action head's pairs and the corners of the kernel family
+    ((2, 8, 16, 70, 240, 1, True, True, False), (2, 8, 16, 576, 160, 1, False, False, False)),     # 4 waves beside 16 (K = 70 | 576)
+    ((2, 8, 16, 240, 160, 3, False, True, True), (2, 8, 8, 160, 160, 1, False, False, False)),     # 3x3 K = 2160 beside a 1x1 on another map
+    ((3, 4, 4, 66, 15, 3, True, True, False), (1, 16, 16, 128, 200, 1, True, False, True)),        # scalar loads (Cin % 4 != 0), ragged tiles
+    ((2, 8, 16, 384, 160, 1, False, False, False), (2, 8, 16, 384, 48, 1, True, True, False)),     # 8 waves | 8 waves
+])
+def test_conv_pair_launch(case, hip_lib, cuda):
+    """[r06] dh_conv2d_pair_f32: two independent skinny-conv layers as ONE launch -- each half bit for bit its own
+    dh_conv2d_f32 launch (its own wave count, its own load form), whatever the other half is; pairs outside the rule are
+    refused and touch nothing."""
+    import ctypes as C
+    from deephar_amd import _lib
+    rng = np.random.default_rng(sum(int(v) for c_ in case for v in c_))
+    keep = []
+    a, ya, want_a = _skinny_args(rng, cuda, *case[0], keep)
+    b, yb, want_b = _skinny_args(rng, cuda, *case[1], keep)
+    assert hip_lib.dh_conv2d_uses_split_k(C.byref(a)) == 1 and hip_lib.dh_conv2d_uses_split_k(C.byref(b)) == 1
+    st = torch.cuda.current_stream().cuda_stream
+    torch.cuda.synchronize()
+    for first, second in ((a, b), (b, a)):
+        ya.fill_(float('nan'))
+        yb.fill_(float('nan'))
+        _lib.check(hip_lib.dh_conv2d_pair_f32(C.byref(first), C.byref(second), st), 'pair')
+        torch.cuda.synchronize()
+        assert torch.equal(ya, want_a) and torch.equal(yb, want_b)
+    # a layer of another kernel family, or one that resamples its input on load: DH_EUNSUPPORTED, nothing written
+    ya.fill_(7.0)
+    yb.fill_(7.0)
+    b.x_resample = 1
+    assert hip_lib.dh_conv2d_pair_f32(C.byref(a), C.byref(b), st) == -2
+    b.x_resample = 0
+    cout = b.Cout
+    b.Cout = 512                                             # more than 256 output channels: not a skinny layer
+    assert hip_lib.dh_conv2d_pair_f32(C.byref(a), C.byref(b), st) in (-1, -2)
+    b.Cout = cout
+    assert hip_lib.dh_conv2d_pair_f32(C.byref(a), None, st) == -1
+    torch.cuda.synchronize()
+    assert bool((ya == 7.0).all()) and bool((yb == 7.0).all())
+
+
 @pytest.mark.parametrize('h,w,c,k', [(32, 32, 64, 5), (16, 16, 32, 5), (8, 8, 32, 3), (40, 64, 32, 3)])
 def test_dwconv_on_channel_slabs(h, w, c, k, hip_lib, cuda):
     """The planner hands the depthwise kernel views into wider tensors (concat slabs): ldx, ldy > C and a channel offset.

@@ -83,7 +83,7 @@ def workloads_block():
         except OSError:
             continue
         r = d['roofline']
-        steps = len(_load('%s_steps_%s.json' % (ROUND, w)))
+        steps = r.get('launches_per_forward') or len(_load('%s_steps_%s.json' % (ROUND, w)))
         cpu = d.get('cpu_baseline', {}).get('value')
         lines.append('| %s | %.0f | %.2f | %s, %s → `%s` | %.3f | %.3f | %s | %d | %s |' % (
             w, d['value'], d['ms_per_step'], ' × '.join(str(v) for v in r['main_shape_mkn']), r['main_shape_epilogue'], r['kernel'],
