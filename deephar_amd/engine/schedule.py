@@ -194,6 +194,10 @@ def assign_streams_tail(plan, deps, items=2, nstreams=2):
             best_s, best, best_placed = s, span, placed
     if best_s == 0 or best > 0.95 * serial:
         return stream, order
+    shift = int(os.environ.get('DEEPHAR_TAIL_SHIFT', '0'))       # A/B aid: move the start of the suffix by this many steps
+    if shift:
+        best_s = min(max(best_s + shift, 1), n - 1)
+        best, best_placed = simulate(best_s)
     if nstreams >= 3:
         # the chain / front-end split is searched jointly with the suffix start: the best two-stream suffix keeps some of
         # the suffix's early steps on stream 0 to balance TWO streams, which is not where three streams balance
