@@ -21,6 +21,10 @@ class ConvArgs(C.Structure):
                                    'up2', 'x_u8', 'w_split', 'res2_down', 'ldyp', 'x_resample')] + [('y_pool', vp)]
 
 
+class ConvSeg(C.Structure):                      # == struct dh_conv_seg
+    _fields_ = [('x2', vp)] + [(n, i32) for n in ('ldx2', 'c_split', 'pool_sh', 'reserved')]
+
+
 class DwArgs(C.Structure):
     _fields_ = [(n, vp) for n in ('x', 'w', 'y', 'pre_scale', 'pre_shift')] + \
                [(n, i32) for n in ('N', 'H', 'W', 'C', 'ldx', 'ldy', 'KH', 'KW', 'PT', 'PL', 'pre_relu', 'up_in')]
@@ -65,6 +69,7 @@ SIGNATURES = {
     'dh_dwconv2d_f32': (C.c_int, [C.POINTER(DwArgs), vp]),
     'dh_conv2d_dw_group_f32': (C.c_int, [C.POINTER(ConvArgs), C.POINTER(DwArgs), vp]),
     'dh_conv2d_pair_f32': (C.c_int, [C.POINTER(ConvArgs), C.POINTER(ConvArgs), vp]),
+    'dh_conv2d_seg_f32': (C.c_int, [C.POINTER(ConvArgs), C.POINTER(ConvSeg), vp]),
     'dh_pool2d_f32': (C.c_int, [C.POINTER(PoolArgs), vp]),
     'dh_upsample2x_add_f32': (C.c_int, [vp, C.c_int, vp, C.c_int, vp, C.c_int] + [C.c_int] * 4 + [vp]),
     'dh_eltwise_f32': (C.c_int, [C.POINTER(EltArgs), vp]),

@@ -10,6 +10,7 @@ using namespace dh;
 static inline hipStream_t S(void* s) { return reinterpret_cast<hipStream_t>(s); }
 // the fields added in round 6 (dh_conv_args.x_resample, dh_dw_args.up_in) sit in what was padding: serialised plans and
 // foreign callers built against the older header keep their layout
+static_assert(sizeof(dh_conv_seg) == 24, "dh_conv_seg layout");
 static_assert(sizeof(dh_conv_args) == 200 && offsetof(dh_conv_args, y_pool) == 192 && offsetof(dh_conv_args, x_resample) == 188,
               "dh_conv_args layout");
 static_assert(sizeof(dh_dw_args) == 88 && offsetof(dh_dw_args, up_in) == 84, "dh_dw_args layout");
@@ -130,16 +131,25 @@ int dh_conv2d_dw_group_f32(const dh_conv_args* a, const dh_dw_args* d, void* str
   return launch_conv_dw_group(*a, *d, S(stream));
 }
 
+// the argument checks dh_conv2d_f32 and launch_conv_igemm make, for the entry points that go to the skinny-conv kernel directly
+static int check_skinny_args(const dh_conv_args* c) {
+  if (c == nullptr || c->x == nullptr || c->w == nullptr || c->y == nullptr) return DH_EINVAL;
+  if ((c->pre_scale == nullptr) != (c->pre_shift == nullptr) || (c->post_scale == nullptr) != (c->post_shift == nullptr)) return DH_EINVAL;
+  if (c->SH <= 0 || c->SW <= 0 || c->KH <= 0 || c->KW <= 0 || c->N <= 0 || c->Cin <= 0 || c->Cout <= 0 || c->OH <= 0 || c->OW <= 0)
+    return DH_EINVAL;
+  if (c->Kp % 32 != 0 || c->Np % 32 != 0 || c->Kp < c->K || c->Np < c->Cout || c->K != c->KH * c->KW * c->Cin) return DH_EINVAL;
+  if ((long long)c->N * c->H * c->W > 0x7fffffffLL || (long long)c->N * c->OH * c->OW * (c->up2 ? 4 : 1) > 0x7fffffffLL) return DH_EINVAL;
+  return DH_OK;
+}
+
 int dh_conv2d_pair_f32(const dh_conv_args* a, const dh_conv_args* b, void* stream) {
-  for (const dh_conv_args* c : {a, b}) {
-    if (c == nullptr || c->x == nullptr || c->w == nullptr || c->y == nullptr) return DH_EINVAL;
-    if ((c->pre_scale == nullptr) != (c->pre_shift == nullptr) || (c->post_scale == nullptr) != (c->post_shift == nullptr)) return DH_EINVAL;
-    if (c->SH <= 0 || c->SW <= 0 || c->KH <= 0 || c->KW <= 0 || c->N <= 0 || c->Cin <= 0 || c->Cout <= 0 || c->OH <= 0 || c->OW <= 0)
-      return DH_EINVAL;
-    if (c->Kp % 32 != 0 || c->Np % 32 != 0 || c->Kp < c->K || c->Np < c->Cout || c->K != c->KH * c->KW * c->Cin) return DH_EINVAL;
-    if ((long long)c->N * c->H * c->W > 0x7fffffffLL || (long long)c->N * c->OH * c->OW * (c->up2 ? 4 : 1) > 0x7fffffffLL) return DH_EINVAL;
-  }
+  if (check_skinny_args(a) != DH_OK || check_skinny_args(b) != DH_OK) return DH_EINVAL;
   return launch_conv_skinny_pair(*a, *b, S(stream));
+}
+
+int dh_conv2d_seg_f32(const dh_conv_args* a, const dh_conv_seg* seg, void* stream) {
+  if (seg == nullptr || check_skinny_args(a) != DH_OK) return DH_EINVAL;
+  return launch_conv_splitk_seg(*a, *seg, S(stream));
 }
 
 int dh_normalize_u8_f32(const uint8_t* x, const float* lut, float* y, int64_t n_pixels, int C, void* stream) {

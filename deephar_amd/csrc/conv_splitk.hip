@@ -36,9 +36,13 @@ constexpr int SK_MAX_CIN = 4096; // prologue table in LDS: 2 x Cin floats
 // `block`: the tile index (blockIdx.x, or the index inside one convolution's range of a paired launch).  A work-group that
 // was launched with more than NWV waves (the pair's other convolution needs them) retires the extra ones here: a wave that
 // has ended no longer counts at s_barrier.
-template <int NWV, bool VEC, int RS>
+// SEG [r06] (dh_conv2d_seg_f32): the input is a concatenation that was never written -- channels [0, c_split) are the 2 x 2
+// maximum (window stride (pool_sh, 2), 'same' padding) of x, stored at [N, H * pool_sh, 2 W, c_split]; channels [c_split, Cin)
+// are x2 as stored, [N, H, W, Cin - c_split].  Every element is read as the maximum of four loads (the same pixel four times
+// for the second segment): one code path, all loads of a chunk in flight together.
+template <int NWV, bool VEC, int RS, bool SEG = false>
 __device__ __forceinline__ void conv_skinny_body(const ConvArgs& p, const unsigned magic_cin, const unsigned magic_kw, float* sk_lds,
-                                                 const int block) {
+                                                 const int block, const ConvSeg seg = ConvSeg{}) {
   float (*red)[4][64] = reinterpret_cast<float (*)[4][64]>(sk_lds);            // [NWV][4][64] partial tiles
   float* pre_tab = sk_lds + NWV * 4 * 64;                                        // [2][Cin4]: scale, shift (BN prologue only)
   const int tid = threadIdx.x;
@@ -51,10 +55,11 @@ __device__ __forceinline__ void conv_skinny_body(const ConvArgs& p, const unsign
   const int n0 = (block % tiles_n) * 16;
   const bool aff = p.pre_scale != nullptr;
   const int cin4 = (p.Cin + 3) & ~3;
-  constexpr int SK_DEPTH = RS >= 2 ? (VEC ? 4 : 2) : (VEC ? 8 : 4);   // k-group quads in flight per wave (dword form: 4 loads per quad and
+  constexpr int SK_DEPTH = (RS >= 2 || SEG) ? (VEC ? 4 : 2) : (VEC ? 8 : 4);   // k-group quads in flight per wave (dword form: 4 loads per quad and
                                                           // lane; pooled input: four pixels per element)
   // physical extent of x, and the pixel pitch between the four pixels of a pooled window
-  const int PH = RS == 1 ? p.H >> 1 : (RS >= 2 ? p.H << 1 : p.H), PW = RS == 1 ? p.W >> 1 : (RS >= 2 ? p.W << 1 : p.W);
+  const int PH = SEG ? p.H * seg.pool_sh : (RS == 1 ? p.H >> 1 : (RS >= 2 ? p.H << 1 : p.H));
+  const int PW = SEG ? p.W << 1 : (RS == 1 ? p.W >> 1 : (RS >= 2 ? p.W << 1 : p.W));
 
   // this lane's output pixel (A operand row) and its top-left input position
   int m = m0 + li;
@@ -64,6 +69,7 @@ __device__ __forceinline__ void conv_skinny_body(const ConvArgs& p, const unsign
   const int oh = rem / p.OW, ow = rem - oh * p.OW;
   const int ih0 = oh * p.SH - p.PT, iw0 = ow * p.SW - p.PL;
   const float* xf = p.x + (size_t)fr * PH * PW * p.ldx;
+  const float* xf2 = SEG && seg.x2 != nullptr ? seg.x2 + (size_t)fr * p.H * p.W * seg.ldx2 : xf;
   const int ncol = n0 + li < p.Np ? n0 + li : p.Np - 1;   // (Np is a multiple of 32: always in range; belt and braces)
   const float* wcol = p.w + (size_t)ncol * 4;             // packed [Kp / 4][Np][4]: unit (k-group, column)
   const int quads = p.Kp / 16;                            // 16 k each: lane group lg takes k-group 4 q + lg
@@ -85,6 +91,22 @@ __device__ __forceinline__ void conv_skinny_body(const ConvArgs& p, const unsign
     if constexpr (RS >= 2) return ok ? (2 * ih * PW + 2 * iw) * p.ldx + c : -1;          // top-left pixel of the 2 x 2 window
     return ok ? (ih * p.W + iw) * p.ldx + c : -1;
   };
+  // SEG: element k -> (base, offset of the window's first pixel, step to the next column, step to the next row); -1 as above
+  auto locate_seg = [&](int k, int& c, const float*& base, int& dcol, int& drow) -> int {
+    const int tap = (int)__umulhi((unsigned)k, magic_cin);
+    c = k - tap * p.Cin;
+    const int kh = (int)(((unsigned)tap * magic_kw) >> 16);
+    const int kw = tap - kh * p.KW;
+    const int ih = ih0 + kh, iw = iw0 + kw;
+    const bool ok = k < p.K && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
+    const bool first = c < seg.c_split;
+    base = first ? xf : xf2;
+    const int r0 = ih * seg.pool_sh;
+    dcol = first ? p.ldx : 0;
+    drow = first && r0 + 1 < PH ? PW * p.ldx : 0;                       // ('same' padding: the last row's window is one row high)
+    if (!ok) return -1;
+    return first ? (r0 * PW + 2 * iw) * p.ldx + c : (ih * p.W + iw) * seg.ldx2 + (c - seg.c_split);
+  };
   // one input element (or float4 of them) through the pooling window
   auto pool4 = [&](float a, float b, float c_, float d) -> float {
     const float mx = fmaxf(fmaxf(a, b), fmaxf(c_, d));
@@ -104,7 +126,19 @@ __device__ __forceinline__ void conv_skinny_body(const ConvArgs& p, const unsign
       const int kg = 4 * (live ? q : 0) + lg;
       fb[d] = *reinterpret_cast<const float4*>(wcol + (size_t)kg * p.Np * 4);
       const int k0 = 4 * kg;
-      if constexpr (VEC) {
+      if constexpr (VEC && SEG) {
+        int c, dcol, drow;
+        const float* base;
+        const int off = locate_seg(k0, c, base, dcol, drow);
+        const bool ok = live && off >= 0;
+        const float* q0 = base + (ok ? off : 0);
+        const float4 v00 = *reinterpret_cast<const float4*>(q0), v01 = *reinterpret_cast<const float4*>(q0 + dcol);
+        const float4 v10 = *reinterpret_cast<const float4*>(q0 + drow), v11 = *reinterpret_cast<const float4*>(q0 + drow + dcol);
+        fa[d] = make_float4(pool4(v00.x, v01.x, v10.x, v11.x), pool4(v00.y, v01.y, v10.y, v11.y),
+                            pool4(v00.z, v01.z, v10.z, v11.z), pool4(v00.w, v01.w, v10.w, v11.w));
+        ch[d] = c;
+        okm |= (ok ? 1u : 0u) << d;
+      } else if constexpr (VEC) {
         int c;
         const int off = locate(k0, c);
         const bool ok = live && off >= 0;
@@ -125,6 +159,16 @@ __device__ __forceinline__ void conv_skinny_body(const ConvArgs& p, const unsign
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           int c;
+          if constexpr (SEG) {
+            int dcol, drow;
+            const float* base;
+            const int off = locate_seg(k0 + j, c, base, dcol, drow);
+            const bool ok = live && off >= 0;
+            const float* q0 = base + (ok ? off : 0);
+            e[j] = pool4(q0[0], q0[dcol], q0[drow], q0[drow + dcol]);
+            okm |= (ok ? 1u : 0u) << (4 * d + j);
+            continue;
+          }
           const int off = locate(k0 + j, c);
           const bool ok = live && off >= 0;
           if constexpr (RS >= 2) {
@@ -228,6 +272,13 @@ template <int NWV, bool VEC, int RS>
 __global__ __launch_bounds__(NWV * 64) void conv_skinny_kernel(const ConvArgs p, const unsigned magic_cin, const unsigned magic_kw) {
   extern __shared__ __attribute__((aligned(16))) float sk_lds[];
   conv_skinny_body<NWV, VEC, RS>(p, magic_cin, magic_kw, sk_lds, (int)blockIdx.x);
+}
+
+template <int NWV, bool VEC>
+__global__ __launch_bounds__(NWV * 64) void conv_skinny_seg_kernel(const ConvArgs p, const ConvSeg seg, const unsigned magic_cin,
+                                                                    const unsigned magic_kw) {
+  extern __shared__ __attribute__((aligned(16))) float sk_lds[];
+  conv_skinny_body<NWV, VEC, 2, true>(p, magic_cin, magic_kw, sk_lds, (int)blockIdx.x, seg);
 }
 
 // [r06] Two INDEPENDENT skinny convolutions in one launch (dh_conv2d_pair_f32): work-groups [0, tiles_a) run the first,
@@ -345,6 +396,36 @@ int launch_conv_skinny_pair(const ConvArgs& a, const ConvArgs& b, hipStream_t s)
     case 16: return launch_pair<16>(a, b, la, lb, s);
     case 8: return launch_pair<8>(a, b, la, lb, s);
     default: return launch_pair<4>(a, b, la, lb, s);
+  }
+}
+
+namespace {
+template <int NWV>
+int launch_seg(const ConvArgs& a, const ConvSeg& seg, const SkinnyLaunch& l, hipStream_t s) {
+  if (l.vec)
+    hipLaunchKernelGGL((conv_skinny_seg_kernel<NWV, true>), dim3((unsigned)l.tiles), dim3(NWV * 64), l.lds, s, a, seg, l.magic_cin, l.magic_kw);
+  else
+    hipLaunchKernelGGL((conv_skinny_seg_kernel<NWV, false>), dim3((unsigned)l.tiles), dim3(NWV * 64), l.lds, s, a, seg, l.magic_cin, l.magic_kw);
+  return check_launch();
+}
+}  // namespace
+
+// dh_conv2d_seg_f32: a skinny-conv layer whose input is concatenate([MaxPooling2D((2, 2), strides=(pool_sh, 2))(x), x2]) read in
+// place.  a.H, a.W: the extent the convolution sees (the pooled one); a.Cin: both segments; a.x_resample must be 0.
+int launch_conv_splitk_seg(const ConvArgs& a, const ConvSeg& seg, hipStream_t s) {
+  if (!conv_is_skinny(a) || a.x_resample || a.res2_down || a.y_pool != nullptr) return DH_EUNSUPPORTED;
+  if (seg.c_split <= 0 || seg.c_split > a.Cin || (seg.pool_sh != 1 && seg.pool_sh != 2) ||
+      (seg.c_split < a.Cin && (seg.x2 == nullptr || seg.ldx2 < a.Cin - seg.c_split)) || a.ldx < seg.c_split)
+    return DH_EINVAL;
+  SkinnyLaunch l;
+  if (skinny_launch_shape(a, &l) != DH_OK) return DH_EINVAL;
+  if ((long long)a.H * seg.pool_sh * a.W * 2 * a.ldx > 0x7fffffffLL || (long long)a.H * a.W * seg.ldx2 > 0x7fffffffLL) return DH_EINVAL;
+  auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
+  l.vec = l.vec && seg.c_split % 4 == 0 && (seg.x2 == nullptr || (seg.ldx2 % 4 == 0 && al16(seg.x2)));
+  switch (l.nwv) {
+    case 16: return launch_seg<16>(a, seg, l, s);
+    case 8: return launch_seg<8>(a, seg, l, s);
+    default: return launch_seg<4>(a, seg, l, s);
   }
 }
 

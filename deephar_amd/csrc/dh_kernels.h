@@ -8,6 +8,7 @@
 namespace dh {
 
 using ConvArgs = dh_conv_args;
+using ConvSeg = dh_conv_seg;
 using DwArgs = dh_dw_args;
 using PoolArgs = dh_pool_args;
 using EltArgs = dh_elt_args;
@@ -26,6 +27,7 @@ int conv_halo_num_cfgs();
 int launch_dwconv(const DwArgs& a, hipStream_t s);
 int launch_conv_dw_group(const ConvArgs& a, const DwArgs& d, hipStream_t s);
 int launch_conv_skinny_pair(const ConvArgs& a, const ConvArgs& b, hipStream_t s);
+int launch_conv_splitk_seg(const ConvArgs& a, const ConvSeg& seg, hipStream_t s);
 int launch_pool(const PoolArgs& a, hipStream_t s);
 int launch_upsample2x_add(const float* a, int lda, const float* b, int ldb, float* y, int ldy, int N, int H,
                           int W, int C, hipStream_t s);

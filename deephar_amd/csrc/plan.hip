@@ -12,7 +12,7 @@ namespace {
 
 using dh::check_launch;
 
-enum Fn { F_CONV, F_DW, F_POOL, F_UPADD, F_ELT, F_SAM, F_CTX, F_DMEANS, F_SAM1D, F_KRON, F_GMM, F_COPY, F_ZPAD, F_DFM, F_SAMCTX, F_NORM, F_GROUP, F_PAIR, F_COUNT };
+enum Fn { F_CONV, F_DW, F_POOL, F_UPADD, F_ELT, F_SAM, F_CTX, F_DMEANS, F_SAM1D, F_KRON, F_GMM, F_COPY, F_ZPAD, F_DFM, F_SAMCTX, F_NORM, F_GROUP, F_PAIR, F_SEG, F_COUNT };
 
 struct Step { int fn; std::vector<unsigned char> payload; };
 struct In { uint64_t tag; size_t items; int u8; char* dst; };   // dst: where dh_forward copies the caller's data (patched)
@@ -136,6 +136,9 @@ int run_step(const Step& st, void* stream) {
     case F_PAIR:
       return dh_conv2d_pair_f32(reinterpret_cast<const dh_conv_args*>(p), reinterpret_cast<const dh_conv_args*>(p + sizeof(dh_conv_args)),
                                 stream);
+    case F_SEG:
+      return dh_conv2d_seg_f32(reinterpret_cast<const dh_conv_args*>(p), reinterpret_cast<const dh_conv_seg*>(p + sizeof(dh_conv_args)),
+                               stream);
     case F_POOL: return dh_pool2d_f32(reinterpret_cast<const dh_pool_args*>(p), stream);
     case F_ELT: return dh_eltwise_f32(reinterpret_cast<const dh_elt_args*>(p), stream);
     case F_SAM: return dh_softargmax2d_f32(reinterpret_cast<const dh_sam_args*>(p), stream);
@@ -235,15 +238,15 @@ int dh_plan_create(const void* blob, size_t blob_bytes, dh_plan** out) {
   // patch the pointers (once)
   for (Step& st : pl->steps) {
     const int np = struct_pointers(st.fn);
-    if (st.fn == F_GROUP || st.fn == F_PAIR) {     // dh_conv_args followed by dh_dw_args (dh_conv2d_dw_group_f32) / by a second
-                                                   // dh_conv_args (dh_conv2d_pair_f32)
-      const size_t second = st.fn == F_GROUP ? sizeof(dh_dw_args) : sizeof(dh_conv_args);
+    if (st.fn == F_GROUP || st.fn == F_PAIR || st.fn == F_SEG) {   // dh_conv_args followed by dh_dw_args (dh_conv2d_dw_group_f32) / by a
+                                                   // second dh_conv_args (dh_conv2d_pair_f32) / by dh_conv_seg (dh_conv2d_seg_f32)
+      const size_t second = st.fn == F_GROUP ? sizeof(dh_dw_args) : (st.fn == F_PAIR ? sizeof(dh_conv_args) : sizeof(dh_conv_seg));
       if (st.payload.size() != sizeof(dh_conv_args) + second) return fail(DH_EINVAL);
       size_t at_off[10 + 1 + 10 + 1];
       int k = 0;
       for (int i = 0; i < 10; ++i) at_off[k++] = (size_t)8 * i;
       at_off[k++] = offsetof(dh_conv_args, y_pool);
-      for (int i = 0; i < (st.fn == F_GROUP ? 5 : 10); ++i) at_off[k++] = sizeof(dh_conv_args) + (size_t)8 * i;
+      for (int i = 0; i < (st.fn == F_GROUP ? 5 : (st.fn == F_PAIR ? 10 : 1)); ++i) at_off[k++] = sizeof(dh_conv_args) + (size_t)8 * i;
       if (st.fn == F_PAIR) at_off[k++] = sizeof(dh_conv_args) + offsetof(dh_conv_args, y_pool);
       for (int i = 0; i < k; ++i) {
         unsigned char* at = st.payload.data() + at_off[i];

@@ -250,6 +250,9 @@ class BoundPlan:
             up = 2 if a['up2'] else 1
             args.N = n * x.lead(3)
             args.H, args.W, args.Cin, args.ldx = x.shape[-3], x.shape[-2], x.C, x.ld
+            sg = a.get('seg')                          # planner rule R14: x = [MaxPooling2D(x) | x2], read in place
+            if sg is not None:                         # (H, W: the extent the convolution sees; Cin: both segments)
+                args.H, args.W, args.Cin = x.shape[-3] // sg['pool_sh'], x.shape[-2] // 2, a['Cin']
             rs = a.get('x_resample', 0)                # planner rule R12: x is stored at another resolution than the conv sees
             if rs:
                 args.x_resample = rs
@@ -257,7 +260,7 @@ class BoundPlan:
             args.OH, args.OW, args.Cout, args.ldy = y.shape[-3] // up, y.shape[-2] // up, a['Cout'], y.ld
             args.KH, args.KW, args.SH, args.SW, args.PT, args.PL = a['kh'], a['kw'], a['sh'], a['sw'], a['pt'], a['pl']
             kp_np = (C.c_int(), C.c_int())
-            _lib.check(lib.dh_conv2d_packed_dims(a['kh'], a['kw'], x.C, a['Cout'], C.byref(kp_np[0]), C.byref(kp_np[1])))
+            _lib.check(lib.dh_conv2d_packed_dims(a['kh'], a['kw'], args.Cin, a['Cout'], C.byref(kp_np[0]), C.byref(kp_np[1])))
             args.K, args.Kp, args.Np = a['K'], kp_np[0].value, kp_np[1].value
             r1, r2 = s.ins.get('res1'), s.ins.get('res2')
             if r1 is not None:
@@ -279,6 +282,15 @@ class BoundPlan:
             args.w, args.w_split = wt.data_ptr(), int(split)
             a['w_split'] = int(split)                  # (read by bench.py to name the kernel)
             self._keep.append(args)
+            if sg is not None:
+                seg = _lib.ConvSeg()
+                x2 = s.ins.get('x2')
+                if x2 is not None:
+                    seg.x2, seg.ldx2 = P(x2), x2.ld
+                seg.c_split, seg.pool_sh = sg['c_split'], sg['pool_sh']
+                self._keep.append(seg)
+                self.calls.append((lib.dh_conv2d_seg_f32, (C.byref(args), C.byref(seg)), s))
+                return
             self.calls.append((lib.dh_conv2d_f32, (C.byref(args), a.get('tile_cfg', -1)), s))
         elif k == 'dwconv':
             x, y = s.ins['x'], s.outs['y']
@@ -648,6 +660,10 @@ class BoundPlan:
         _lib.check(lib.dh_event_create(C.byref(e1)))
         for i, (fn, args, step) in enumerate(self.calls):
             if step.kind not in ncfgs:
+                continue
+            if fn is lib.dh_conv2d_seg_f32:                      # (skinny-conv kernel by its own entry point: nothing to choose)
+                step.attrs['tile_cfg'] = -1
+                step.attrs['split_k'] = True
                 continue
             ncfg = ncfgs[step.kind]
             cargs = args[0]._obj

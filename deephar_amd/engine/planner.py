@@ -482,6 +482,7 @@ class Planner:
         self._merge_sibling_pointwise()
         self._merge_siblings_into_joint_buffers()
         self._merge_sibling_pools()
+        self._pool_into_segmented_conv()
         self._collect_params()
         from . import schedule
         schedule.finalize(self.plan, self.nstreams, self.stream_policy)
@@ -741,6 +742,55 @@ class Planner:
             for v in (ya, yb, y):
                 self.producer[id(v)] = merged
             # (the merged step may pair again with a third sibling further down; i now holds the next step)
+
+    # ---- R14: a pooling that fills the first channels of a concatenation read by one skinny convolution -------------
+    def _pool_into_segmented_conv(self):
+        """[r06] `concat_tensorlist([x1, x2, xa])` in front of the action head's second residual unit (spnet.py:126-141): x1, x2
+        are poolings (one launch out of a joint buffer after R13), xa the features of the previous head; the only reader is
+        the unit's merged shortcut | conv1 launch (R10c), a layer of the skinny-conv kernel.  That kernel takes the maximum of
+        the window while it gathers the first c_split channels of its input and reads the rest where they are
+        (dh_conv2d_seg_f32): the pooled tensor is never written, one launch less per head.  Bit-identical.
+        DEEPHAR_POOL_SEGMENTS=0 switches it off."""
+        if os.environ.get('DEEPHAR_POOL_SEGMENTS', '1') == '0':
+            return
+        steps = self.plan.steps
+        i = 0
+        while i < len(steps):
+            p = steps[i]
+            i += 1
+            a = p.attrs
+            if p.kind != 'pool' or a.get('mode', 0) != 0 or (a['kh'], a['kw'], a['sw'], a['pt'], a['pl']) != (2, 2, 2, 0, 0) or \
+                    a['sh'] not in (1, 2):
+                continue
+            x, y = p.ins['x'], p.outs['y']
+            if len(x.shape) < 3 or x.coff != 0 or x.ld != x.C or x.buf.pinned or y.coff != 0 or y.buf.pinned or x.C % 4 or \
+                    x.shape[-2] != 2 * y.shape[-2] or x.shape[-3] != a['sh'] * y.shape[-3]:
+                continue
+            if any(v is not None and v.buf is x.buf for q in steps if q is not p for v in q.ins.values()):
+                continue                                   # somebody else reads the un-pooled tensor
+            readers = [(q, r) for q in steps for r, v in q.ins.items() if v is not None and v.buf is y.buf]
+            if len(readers) != 1 or readers[0][1] != 'x':
+                continue
+            q = readers[0][0]
+            cx = q.ins['x']
+            qa = q.attrs
+            if q.kind != 'conv' or qa.get('x_resample') or qa.get('up2') or qa.get('res2_down') or 'ypool' in q.outs or \
+                    cx.coff != 0 or cx.ld != y.ld or cx.C < y.C or cx.shape[:-1] != y.shape[:-1] or qa['Cin'] != cx.C:
+                continue
+            oy = q.outs['y']
+            if not split_k_rule(oy.shape[-3] * oy.shape[-2] if len(oy.shape) >= 3 else 1, qa['K'], qa['Cout'], qa['Cin'], qa['kh'],
+                                qa['kw']):
+                continue
+            # the other writers of the concatenation fill channels behind the pooled run (or there are none)
+            others = [v for w in steps if w is not p for v in w.outs.values() if v is not None and v.buf is y.buf]
+            if any(v.coff < y.C or v.ld != y.ld for v in others) or (cx.C > y.C) != bool(others) or (cx.C - y.C) % 4:
+                continue
+            q.ins['x'] = x
+            if cx.C > y.C:
+                q.ins['x2'] = Value(cx.shape[:-1] + (cx.C - y.C,), y.buf, y.C, y.ld)
+            qa['seg'] = dict(c_split=y.C, pool_sh=a['sh'])
+            steps.remove(p)
+            i -= 1
 
     # ---- R3: add([a, UpSampling2D(b)]) as the second residual of the convolution that produces a --------------
     def _upsampled_residual(self, t):

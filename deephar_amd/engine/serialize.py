@@ -29,7 +29,7 @@ FUNCTIONS = ['dh_conv2d_f32', 'dh_dwconv2d_f32', 'dh_pool2d_f32', 'dh_upsample2x
              'dh_softargmax2d_f32', 'dh_context_aggregation_f32', 'dh_depth_means_f32', 'dh_softargmax1d_f32',
              'dh_kronecker_f32', 'dh_global_maxmin_softmax_f32', 'dh_copy_channels_f32', 'dh_zeropad2d_f32',
              'dh_depth_from_maps_f32', 'dh_softargmax2d_context_f32', 'dh_normalize_u8_f32', 'dh_conv2d_dw_group_f32',
-             'dh_conv2d_pair_f32']
+             'dh_conv2d_pair_f32', 'dh_conv2d_seg_f32']
 ARENA, WEIGHTS, BYTES = 1, 2, 3
 
 

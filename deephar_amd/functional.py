@@ -45,7 +45,7 @@ def pack_conv_weight(w_hwio, device='cuda'):
 
 def conv2d(x, w_hwio, strides=(1, 1), padding='same', pre_scale=None, pre_shift=None, pre_relu=False,
            post_scale=None, post_shift=None, post_relu=False, res1=None, res2=None, up2=False, tile_cfg=-1,
-           packed=None, in_lut=None, split=False, halo=False, res2_down=False, pool2=False, x_resample=0):
+           packed=None, in_lut=None, split=False, halo=False, res2_down=False, pool2=False, x_resample=0, seg=None):
     """Fused conv (see dh_conv2d_f32).  x [N,H,W,Cin]; w_hwio numpy [kh,kw,Cin,Cout].  A uint8 `x` needs
     `in_lut` (float32 [Cin,256] device tensor, engine.executor.normalization_lut): bytes are normalised on load."""
     torch = _t()
@@ -60,7 +60,13 @@ def conv2d(x, w_hwio, strides=(1, 1), padding='same', pre_scale=None, pre_shift=
     lib = _lib.load()
     kh, kw, cin, cout = w_hwio.shape
     n, h, w_, c = x.shape
-    assert c == cin
+    if seg is not None:        # dh_conv2d_seg_f32: seg = (x2 or None, pool_sh): the input is [maxpool(x, strides (pool_sh, 2)) | x2]
+        x2, pool_sh = seg
+        _chk(x2)
+        assert c + (x2.shape[-1] if x2 is not None else 0) == cin and h % pool_sh == 0 and w_ % 2 == 0
+        h, w_ = h // pool_sh, w_ // 2
+    else:
+        assert c == cin
     if x_resample:             # dh_conv_args.x_resample: x is stored at half (1) / double (2, 3) the resolution the conv sees
         h, w_ = (2 * h, 2 * w_) if x_resample == 1 else (h // 2, w_ // 2)
     if padding == 'same':
@@ -83,7 +89,7 @@ def conv2d(x, w_hwio, strides=(1, 1), padding='same', pre_scale=None, pre_shift=
     a.x, a.w, a.y = _p(x), _p(wt), _p(y)
     a.pre_scale, a.pre_shift, a.post_scale, a.post_shift = _p(pre_scale), _p(pre_shift), _p(post_scale), _p(post_shift)
     a.res1, a.res2 = _p(res1), _p(res2)
-    a.N, a.H, a.W, a.Cin, a.ldx = n, h, w_, cin, cin
+    a.N, a.H, a.W, a.Cin, a.ldx = n, h, w_, cin, c
     a.OH, a.OW, a.Cout, a.ldy = oh, ow, cout, cout
     a.KH, a.KW, a.SH, a.SW, a.PT, a.PL = kh, kw, strides[0], strides[1], pt, pl
     a.K, a.Kp, a.Np = kh * kw * cin, kp, np_
@@ -98,6 +104,13 @@ def conv2d(x, w_hwio, strides=(1, 1), padding='same', pre_scale=None, pre_shift=
     if pool2:                                    # second output: MaxPooling2D((2, 2)) of y (dh_conv_args.y_pool)
         yp = torch.empty((n, oh // 2, ow // 2, cout), dtype=torch.float32, device=x.device)
         a.y_pool, a.ldyp = _p(yp), cout
+    if seg is not None:
+        sg = _lib.ConvSeg()
+        if x2 is not None:
+            sg.x2, sg.ldx2 = _p(x2), x2.shape[-1]
+        sg.c_split, sg.pool_sh = c, pool_sh
+        _lib.check(lib.dh_conv2d_seg_f32(C.byref(a), C.byref(sg), _stream()), 'dh_conv2d_seg_f32')
+        return y
     _lib.check(lib.dh_conv2d_f32(C.byref(a), tile_cfg, _stream()), 'dh_conv2d_f32')
     return (y, yp) if pool2 else y
 

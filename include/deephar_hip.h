@@ -185,6 +185,25 @@ int dh_dwconv2d_f32(const dh_dw_args* a, void* stream);
  * (exp/pennaction/eval_speed2d.py).  DH_EUNSUPPORTED for any pair outside that description (call the two entry points). */
 int dh_conv2d_dw_group_f32(const dh_conv_args* conv, const dh_dw_args* dw, void* stream);
 
+/* [r06] A skinny-conv layer (dh_conv2d_uses_split_k) whose input is a concatenation that is never written out:
+ *   concatenate([MaxPooling2D((2, 2), strides=(pool_sh, 2), padding='same')(x), x2])
+ * -- SPNet's action head pools its pose and appearance features and concatenates them with the features handed on by the
+ * previous head in front of its second residual unit (deephar/models/spnet.py:126-141: x1, x2 = maxpooling2d(...);
+ * concat_tensorlist([x1, x2, xa]); residual(...)).  `a` describes the convolution as dh_conv2d_f32 would see the concatenated
+ * tensor (H, W: the pooled extent; Cin: all channels; ldx: the pixel pitch of x; x_resample = 0); `seg` says where the second
+ * run of channels lives.  x is [N, H * pool_sh, 2 W, c_split] (pool_sh = 1: windows of two rows starting at EVERY row, the last
+ * one a single row -- the reference's time_stride = 1 for clips shorter than 16 frames; pool_sh = 2: disjoint windows).  The
+ * BatchNormalization / ReLU prologue and the zero padding act on the concatenated pixels: bit for bit dh_conv2d_f32 on the
+ * tensor a pooling launch and the concatenation would have written. */
+typedef struct dh_conv_seg {
+  const float* x2;   /* channels [c_split, Cin): [N, H, W, Cin - c_split], pixel pitch ldx2; may be NULL when c_split == Cin */
+  int32_t ldx2;
+  int32_t c_split;   /* channels [0, c_split) are the pooled x */
+  int32_t pool_sh;   /* 1 or 2: row stride of the pooling window (its column stride is 2) */
+  int32_t reserved;  /* 0 */
+} dh_conv_seg;
+int dh_conv2d_seg_f32(const dh_conv_args* a, const dh_conv_seg* seg, void* stream);
+
 /* [r06] Two INDEPENDENT convolutions with a tiny output map in ONE launch -- in SPNet's action head (deephar/models/spnet.py:
  * 113-133) the residual unit on the pose features and `conv2d(af, num_visual_features, (1, 1))` on the appearance features
  * meet only at the concatenation behind them.  Both must be layers of the skinny-conv kernel (dh_conv2d_uses_split_k), read

@@ -274,6 +274,7 @@ def test_sibling_pools_merged_are_bit_identical(hip_lib, cuda, monkeypatch):
     moved -- 2-D replica model, one and two streams, 8-frame clips (window stride (1, 2)) and 16-frame clips (stride (2, 2));
     the 17-joint 3-D model zero-pads its features to 20 joints in front of the pooling (spnet.py:124-132): ZeroPadding2D writes
     dense rows, the rule leaves those heads alone."""
+    monkeypatch.setenv('DEEPHAR_POOL_SEGMENTS', '0')          # (rule R14 would read the joint pooling through its consumer)
     for frames, seed in ((8, 41), (16, 43)):
         clips = np.random.default_rng(seed).uniform(-1, 1, (2, frames, 128, 128, 3)).astype(np.float32)
         for layout, nact, rep in (('pa16j2d', 15, True), ('pa17j3d', 60, False)):
@@ -324,7 +325,34 @@ def test_paired_skinny_convs_are_bit_identical(hip_lib, cuda, monkeypatch):
     m.predict(big, batch_size=72)
     assert len(m.executor.bound[72].paired) < len(bp.paired)      # (rows of the bound batch decide: beyond the latency regime, apart)
     from deephar_amd.engine import serialize
-    assert serialize.FUNCTIONS[-1] == 'dh_conv2d_pair_f32'
+    assert 'dh_conv2d_pair_f32' in serialize.FUNCTIONS
+
+
+def test_pool_read_by_segmented_conv_is_bit_identical(hip_lib, cuda, monkeypatch):
+    """[r06] Planner rule R14: the pooled features of an action head (one joint launch after R13) are never written -- the
+    head's second residual unit reads concatenate([pool(U), xa]) through dh_conv2d_seg_f32: one launch less per head, not one
+    bit moved; 2-D replica model and 17-joint 3-D model (ZeroPadding2D in front of its poolings: R13 does not apply, the first
+    pooling alone is read through) at 8- and 16-frame clips (window stride (1, 2) / (2, 2)), one and two streams."""
+    for frames, seed in ((8, 51), (16, 53)):
+        clips = np.random.default_rng(seed).uniform(-1, 1, (2, frames, 128, 128, 3)).astype(np.float32)
+        for layout, nact, rep in (('pa16j2d', 15, True), ('pa17j3d', 60, False)):
+            monkeypatch.setenv('DEEPHAR_POOL_SEGMENTS', '0')
+            base, _, _, _ = _spnet(frames, layout, nact, 2, [1, 2], 160, replica=rep, res=128)
+            want = base.predict(clips, batch_size=2)
+            nbase = len(base.plan.steps)
+            monkeypatch.setenv('DEEPHAR_POOL_SEGMENTS', '1')
+            for streams, policy in ((1, 'list'), (2, 'tail')):
+                m, _, _, _ = _spnet(frames, layout, nact, 2, [1, 2], 160, replica=rep, res=128)
+                m.num_streams, m.stream_policy = streams, policy
+                seg = [s for s in m.plan.steps if s.kind == 'conv' and s.attrs.get('seg')]
+                # 2-D: the joint pooling of both feature sets (320 channels); 3-D: the pooling of the (zero-padded) pose features
+                # alone -- the appearance features' pooling still writes its run of the concatenation, which is then part of x2
+                csplit = 320 if layout == 'pa16j2d' else 160
+                assert len(seg) == 6 and len(m.plan.steps) == nbase - 6, (layout, len(seg), len(m.plan.steps), nbase)
+                assert all(s.attrs['seg'] == dict(c_split=csplit, pool_sh=1 if frames == 8 else 2) for s in seg)
+                assert sum(1 for s in seg if 'x2' in s.ins) == (5 if layout == 'pa16j2d' else 6)      # the first 2-D head has no xa
+                for a, b in zip(want, m.predict(clips, batch_size=2)):
+                    assert np.array_equal(a, b), (frames, layout, streams)
 
 
 def test_pose_times_confidence_folded_into_the_read_out(hip_lib, cuda, monkeypatch):

@@ -404,6 +404,45 @@ def test_conv_pair_launch(case, hip_lib, cuda):
     assert bool((ya == 7.0).all()) and bool((yb == 7.0).all())
 
 
+@pytest.mark.parametrize('case', [
+    # n, h (pooled), w (pooled), c pooled, c direct, cout, k, pool_sh, bn prologue, residual
+    (2, 8, 8, 320, 160, 200, 1, 1, True, False),      # the action head's r2 unit at T = 8: [x1 | x2 | xa] -> shortcut | conv1
+    (2, 8, 8, 320, 0, 240, 1, 1, True, False),        # the first head: no features handed on
+    (3, 8, 8, 320, 160, 200, 1, 2, True, True),       # T = 16: disjoint windows
+    (2, 4, 8, 64, 32, 48, 3, 1, False, True),         # 3 x 3: zero padding acts on the concatenated pixels
+    (1, 8, 4, 66, 30, 15, 3, 2, True, False),         # scalar loads (c_split % 4 != 0), ragged tiles
+])
+def test_skinny_conv_reads_pooled_and_direct_segments(case, hip_lib, cuda):
+    """[r06] dh_conv2d_seg_f32: the input of a skinny-conv layer is concatenate([MaxPooling2D((2, 2), strides=(pool_sh, 2),
+    'same')(x), x2]) read in place (spnet.py:126-141) -- bit for bit dh_conv2d_f32 on the tensor the pooling kernel and a
+    concatenation write; layers outside the skinny-conv rule and malformed segments are refused."""
+    import ctypes as C
+    from deephar_amd import functional as F, _lib
+    n, h, w, cp, cd, cout, ks, sh, bn, res = case
+    rng = np.random.default_rng(sum(int(v) for v in case))
+    x = _rand(rng, (n, h * sh, 2 * w, cp))
+    x2 = _rand(rng, (n, h, w, cd)) if cd else None
+    cin = cp + cd
+    k = _rand(rng, (ks, ks, cin, cout), np.sqrt(1.0 / (ks * ks * cin)))
+    d = lambda a: None if a is None else torch.from_numpy(a).to(cuda)
+    ps, pb = (d(rng.uniform(0.5, 1.5, cin).astype(np.float32)), d(_rand(rng, (cin,), 0.3))) if bn else (None, None)
+    qs, qb = d(rng.uniform(0.5, 1.5, cout).astype(np.float32)), d(_rand(rng, (cout,), 0.3))
+    r1 = d(_rand(rng, (n, h, w, cout))) if res else None
+    kw = dict(pre_scale=ps, pre_shift=pb, pre_relu=True, post_scale=qs, post_shift=qb, res1=r1, post_relu=not res)
+    xd, x2d = d(x), d(x2)
+    pooled = F.pool2d(xd, (2, 2), (sh, 2), 'same')
+    assert pooled.shape == (n, h, w, cp)
+    cat = torch.cat([pooled, x2d], dim=-1).contiguous() if cd else pooled
+    want = F.conv2d(cat, k, **kw)
+    got = F.conv2d(xd, k, seg=(x2d, sh), **kw)
+    assert torch.equal(got, want)
+    # refusals: an up-sampling epilogue, a layer of another family (Cout > 256), a split point outside the channels
+    with pytest.raises(Exception):
+        F.conv2d(xd, _rand(rng, (ks, ks, cin, 512), 0.1), seg=(x2d, sh), pre_relu=True)
+    with pytest.raises(Exception):
+        F.conv2d(xd, k, seg=(x2d, 3), **kw)
+
+
 @pytest.mark.parametrize('h,w,c,k', [(32, 32, 64, 5), (16, 16, 32, 5), (8, 8, 32, 3), (40, 64, 32, 3)])
 def test_dwconv_on_channel_slabs(h, w, c, k, hip_lib, cuda):
     """The planner hands the depthwise kernel views into wider tensors (concat slabs): ldx, ldy > C and a channel offset.

@@ -626,15 +626,17 @@ def test_round6_planner_rules_on_the_host(monkeypatch):
 
     def plan(**env):
         for k in ('DEEPHAR_MERGE_KXK', 'DEEPHAR_MERGE_SIBLINGS', 'DEEPHAR_UP_COMMUTE', 'DEEPHAR_RESAMPLE_ON_LOAD', 'DEEPHAR_FOLD_POSE_MUL',
-                  'DEEPHAR_MERGE_POOLS', 'DEEPHAR_FUSE_POOL_SMALL'):
+                  'DEEPHAR_MERGE_POOLS', 'DEEPHAR_FUSE_POOL_SMALL', 'DEEPHAR_POOL_SEGMENTS'):
             monkeypatch.setenv(k, env.get(k, '1'))
         full = bench.build_speed2d()
         m = Model(full.input, full.outputs[34:36])
         return m, m.plan
     _, off = plan(DEEPHAR_MERGE_KXK='0', DEEPHAR_MERGE_SIBLINGS='0', DEEPHAR_UP_COMMUTE='0', DEEPHAR_RESAMPLE_ON_LOAD='0',
-                  DEEPHAR_FOLD_POSE_MUL='0', DEEPHAR_MERGE_POOLS='0', DEEPHAR_FUSE_POOL_SMALL='0')
+                  DEEPHAR_FOLD_POSE_MUL='0', DEEPHAR_MERGE_POOLS='0', DEEPHAR_FUSE_POOL_SMALL='0', DEEPHAR_POOL_SEGMENTS='0')
     m, on = plan()
-    assert len(off.steps) == 604 and len(on.steps) == 431
+    assert len(off.steps) == 604 and len(on.steps) == 413
+    _, r13 = plan(DEEPHAR_POOL_SEGMENTS='0')
+    assert len(r13.steps) == 431
     # R10b: eighteen action heads, each opens with ONE 3x5 convolution of 70 columns whose parts sit centred in the window
     kxk = [s for s in on.steps if s.kind == 'conv' and (s.name or '').count('p_conv0') == 3]
     assert len(kxk) == 18 and all((s.attrs['kh'], s.attrs['kw'], s.attrs['pt'], s.attrs['pl'], s.attrs['Cout'], s.attrs['K']) ==
@@ -673,12 +675,21 @@ def test_round6_planner_rules_on_the_host(monkeypatch):
     assert sum(1 for s in off.steps if s.kind == 'eltwise') == 18 and not any(s.kind == 'eltwise' for s in on.steps)
     assert sum(1 for s in on.steps if s.kind == 'sam' and s.attrs.get('xy_times_conf')) == 18
     # R13: every action head pools its pose and appearance features in one launch out of a joint buffer
-    pools = [s for s in on.steps if s.kind == 'pool' and '+' in (s.name or '')]
+    pools = [s for s in r13.steps if s.kind == 'pool' and '+' in (s.name or '')]
     assert len(pools) == 18 and all(s.ins['x'].shape == (8, 16, 320) and s.outs['y'].shape == (8, 8, 320) for s in pools)
     for s in pools[:3]:
-        writers = [q for q in on.steps for v in q.outs.values() if v is not None and v.buf is s.ins['x'].buf]
+        writers = [q for q in r13.steps for v in q.outs.values() if v is not None and v.buf is s.ins['x'].buf]
         assert sorted((v.coff, v.C) for q in writers for v in q.outs.values() if v.buf is s.ins['x'].buf) == [(0, 160), (160, 160)]
-        assert all(on.steps.index(q) < on.steps.index(s) for q in writers)
+        assert all(r13.steps.index(q) < r13.steps.index(s) for q in writers)
+    # R14: that pooling is read through by the head's r2 unit -- concatenate([pool(U), xa]) as (x, x2) of one convolution
+    segs = [s for s in on.steps if s.kind == 'conv' and s.attrs.get('seg')]
+    assert len(segs) == 18 and not any(s.kind == 'pool' and '+' in (s.name or '') for s in on.steps)
+    assert all(s.attrs['seg'] == dict(c_split=320, pool_sh=1) and s.ins['x'].shape == (8, 16, 320) and s.outs['y'].shape[:2] == (8, 8)
+               for s in segs)
+    assert sorted(s.attrs['Cin'] for s in segs) == [320] + [480] * 17 and sum(1 for s in segs if 'x2' in s.ins) == 17
+    for s in segs:
+        if 'x2' in s.ins:
+            assert (s.ins['x2'].coff, s.ins['x2'].C, s.ins['x2'].ld) == (320, 160, 480)
     # R7 at 16 / 8 columns: the down-scaling units' MaxPooling2D is the second output of the prediction block's conv2
     pooled = [s for s in on.steps if s.kind == 'conv' and 'ypool' in s.outs]
     assert sorted(s.outs['y'].shape[-2] for s in pooled) == [8] * 3 + [16] * 3 + [32] * 2 and \
