@@ -222,6 +222,8 @@ def test_siblings_merged_into_joint_buffers_are_bit_identical(hip_lib, cuda, mon
     part has a BatchNormalization and the odd ReLU moved into its reader's prologue: fewer launches, not one bit moved;
     2-D replica model and 3-D model, one and two streams; weights set after the first predict reach the merged launch."""
     from deephar_amd.engine.planner import ConcatAffine
+    monkeypatch.setenv('DEEPHAR_POOL_SEGMENTS', '0')          # (rule R14 needs the merged unit as the concatenation's ONLY reader:
+                                                              #  it would take six more launches out of the merged plans alone)
     clips = np.random.default_rng(33).uniform(-1, 1, (2, 8, 128, 128, 3)).astype(np.float32)
     for layout, nact, rep in (('pa16j2d', 15, True), ('pa17j3d', 60, False)):
         monkeypatch.setenv('DEEPHAR_MERGE_SIBLINGS', '0')
