@@ -16,8 +16,8 @@ Fusion rules (what the reference leaves to TensorFlow as separate kernels):
                 epilogue at 2x resolution; a free-standing UpSampling2D -> add becomes one upsample_add kernel.
   R4 concat   : producers write straight into the concatenation buffer at their channel offset
                 (reception.py:75,83,87); Lambda channel slices are pointer/ld views (reception.py:171-172).
-  R7 pool     : MaxPooling2D((2, 2)) of a 32-column convolution output is a second output of that convolution's epilogue
-                (dh_conv_args.y_pool; reception.py:105-116).
+  R7 pool     : MaxPooling2D((2, 2)) of a 32-column convolution output -- [r06] also of a 16- or 8-column one -- is a second
+                output of that convolution's epilogue (dh_conv_args.y_pool; reception.py:105-116, common.py:70-86).
   R9 wide add : add([...]) with four or more operands is re-associated into one add per convolution that produces an operand
                 (SPNet's re-injection sum, spnet.py:233), a second two-operand add behind a residual add takes the free
                 residual slot (spnet.py:303) -- no element-wise launches are left for either.
@@ -33,6 +33,12 @@ Fusion rules (what the reference leaves to TensorFlow as separate kernels):
                 half-resolution second residual of the separable convolution's pointwise half, dh_conv_args.res2_down) and
                 the depthwise half reads the half-resolution tensor as if up-sampled (dh_dw_args.up_in).  Same products, same
                 sums; only the order of the two residual additions changes.
+  R13 pools   : [r06] two poolings with the same window whose results are concatenated right away (the action head's pose and
+                appearance features, spnet.py:126-139) read ONE joint buffer their producers fill and are one launch.
+  R14 segments: [r06] a pooling that fills the first channels of a concatenation whose only reader is a convolution on the
+                skinny-conv kernel (the head's second residual unit, spnet.py:139-141) is not written out: that kernel reads
+                concatenate([pool(x), x2]) in place (dh_conv2d_seg_f32).  Bit-identical.
+  (R10 / R10b / R10c: sibling convolutions of one tensor merged into one launch -- see the passes below.)
 All tensors are fp32; sizes are tracked per batch item so one plan serves any batch size.
 """
 import os
