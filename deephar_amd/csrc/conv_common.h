@@ -163,7 +163,10 @@ struct EpiNoHook {
 // PRE: the caller issued EpiPrefetch::issue() (and the tiling holds a prefetched tile)
 // `staged` runs once the last row block's accumulators sit in the LDS slab (their registers are free from there on):
 // a kernel that finishes its tile in several column slices puts the next slice's residual prefetch there.
-template <int WM, int WN, int TM, int TN, bool UP2, bool PRE, typename HOOK = EpiNoHook, bool DIRECT_R2 = true>
+// CHROWS > 0: the row loop of the LDS-slab path runs in chunks of CHROWS iterations, each chunk loading ITS residual rows
+// first (instead of every residual row of the block before the first store): a kernel whose accumulators leave few
+// registers (the split-bf16 wide tiling holds 96 of them for its other column slice) does not spill.
+template <int WM, int WN, int TM, int TN, bool UP2, bool PRE, typename HOOK = EpiNoHook, bool DIRECT_R2 = true, int CHROWS = 0>
 __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x16 (&acc)[TM][TN], float* smem, int m0,
                                               int n0, int M, int epi_vec, const EpiPrefetch<TM, TN>& pre,
                                               HOOK staged = HOOK()) {
@@ -263,7 +266,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x16 (&acc)[T
           sh[q] = *reinterpret_cast<const float4*>(p.post_shift + ncol[q]);
         }
       }
-      if constexpr (!kPre) {
+      if constexpr (!kPre && CHROWS == 0) {
         if (p.res1 != nullptr) {
 #pragma unroll
           for (int it = 0; it < IT; ++it) {
@@ -276,12 +279,23 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x16 (&acc)[T
       // second residual (read at OUTPUT resolution): also loaded before the first store -- the compiler must
       // assume y may alias res2 and would otherwise keep every load behind the previous iteration's store, one
       // memory round trip per row.  Up-sampling writes (and reads) 4 positions per row: chunks of CH rows.
-      constexpr int CH = UP2 ? (IT < 4 ? IT : 4) : IT;     // rows per chunk: <= 16 float4 of res2 in flight
+      constexpr int CH = UP2 ? (IT < 4 ? IT : 4) : (CHROWS > 0 && CHROWS < IT ? CHROWS : IT);     // rows per chunk: <= 16 float4 of res2 in flight
+      static_assert(IT % CH == 0, "chunks of equal size");
       constexpr int ND = UP2 ? 4 : 1;
 #pragma unroll
       for (int c0 = 0; c0 < IT; c0 += CH) {
         float4 r2[CH][ND];
         size_t mo[CH][ND];
+        if constexpr (!kPre && CHROWS > 0) {             // this chunk's first-residual rows
+          if (p.res1 != nullptr) {
+#pragma unroll
+            for (int u = 0; u < CH; ++u) {
+              const int row = (lane + 64 * (c0 + u)) / ROW4;
+              const int m = m0 + (wm * TM + i) * 32 + row;
+              rr[c0 + u] = ld4_stream(p.res1 + (size_t)(m < M ? m : M - 1) * p.ldr1 + ncol[(c0 + u) % NSC]);
+            }
+          }
+        }
 #pragma unroll
         for (int u = 0; u < CH; ++u) {
           const int it = c0 + u;

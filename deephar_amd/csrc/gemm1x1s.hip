@@ -21,6 +21,10 @@ namespace dh {
 namespace {
 
 constexpr int BK = 32;
+#ifndef DH_WIDE_CHROWS
+#define DH_WIDE_CHROWS 6
+#endif
+constexpr int WIDE_CHROWS = DH_WIDE_CHROWS;   // epilogue rows per chunk of the wide tiling (see conv_epilogue)
 
 typedef __attribute__((address_space(3))) void* lptr_t;
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -627,8 +631,8 @@ __global__ __launch_bounds__(WM * 64, 2) void gemm1x1s_wide_kernel(const ConvArg
   // columns 0-95 (residual rows requested during the last K-step), then 96-191 through the same slab.  Holding the
   // second slice's residual rows in registers across the first slice's row loop spills (measured: 80 dwords); its
   // round trip is covered by the other work-group of the CU instead.
-  conv_epilogue<WM, 1, 1, 3, UP2, true>(p, acc[0], smem, m0, n0, M, epi_vec, pre0);
-  conv_epilogue<WM, 1, 1, 3, UP2, false>(p, acc[1], smem, m0, n0 + 96, M, epi_vec, pre0);
+  conv_epilogue<WM, 1, 1, 3, UP2, true, EpiNoHook, true, WIDE_CHROWS>(p, acc[0], smem, m0, n0, M, epi_vec, pre0);
+  conv_epilogue<WM, 1, 1, 3, UP2, false, EpiNoHook, true, WIDE_CHROWS>(p, acc[1], smem, m0, n0 + 96, M, epi_vec, pre0);
 }
 
 template <int WM, bool UP2, bool RELU, bool KXK>

@@ -102,7 +102,8 @@ def pmc_entry(args, w, base, roof, cfg, kname):
              source='rocprofv3 --pmc, FETCH_SIZE(+MFMA busy, GUI active) and WRITE_SIZE in separate passes over `python '
                     'bench.py --workload %s --replay-step %d%s` (tools/profile_round.py): the last %d dispatches = the '
                     'in-model launch replayed; FETCH_SIZE / WRITE_SIZE are KiB, FETCH_SIZE x2 on gfx950 '
-                    '(MI355X_MICROARCH.md, HBM section)' % (w, roof['main_shape_step_index'],
+                    '(MI355X_MICROARCH.md, HBM section)' % (w + (' ' + args.bench_args if args.bench_args else ''),
+                                                            roof['main_shape_step_index'],
                                                             '' if cfg is None else ' --replay-cfg %d' % cfg, REPS))
     e['traffic_over_algorithmic'] = round((e['fetch_bytes_per_launch'] + e['write_bytes_per_launch']) /
                                           e['algorithmic_bytes_per_launch'], 4)
@@ -119,6 +120,7 @@ def main():
     ap.add_argument('--skip-pmc', action='store_true')
     ap.add_argument('--skip-stats', action='store_true')
     ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--bench-args', default='', help="extra bench.py arguments for every run, e.g. '--gemm bf16x3'")
     ap.add_argument('--all-tilings', default='mpii,h36m',
                     help='workloads whose dominant GEMM is PMC-profiled on all three <4,1,1,N> tilings (2 passes each)')
     args = ap.parse_args()
@@ -129,7 +131,7 @@ def main():
         tune = os.path.join(OUT, '%s_tune_%s.json' % (args.tag, w))
         if os.path.exists(tune):
             os.remove(tune)
-        base = [py, bench, '--workload', w, '--tune-cache', tune]
+        base = [py, bench, '--workload', w, '--tune-cache', tune] + args.bench_args.split()
         # (1) the line (full default line for mpii: predict boundary, bf16x3 and clip legs, CPU baseline)
         log = os.path.join(OUT, '%s_bench_%s.log' % (args.tag, w))
         sh(base + ['--steps', str(args.steps), '--warmup', '3', '--dump-steps', os.path.join(OUT, '%s_steps_%s.json' % (args.tag, w))],
