@@ -283,6 +283,9 @@ def epilogue_tag(s):
     return '+'.join(parts) or 'plain'
 
 
+ABSORBED = set()      # id() of the steps of the last profiled plans whose work runs inside a grouped / paired launch
+
+
 def real_launches(bound):
     """Kernel launches of one forward: the plan's steps minus those a grouped / paired launch absorbed
     (BoundPlan.group_launches: dh_conv2d_dw_group_f32, dh_conv2d_pair_f32)."""
@@ -292,9 +295,11 @@ def real_launches(bound):
 def profile_plans(bound):
     """bound: [(BoundPlan, stream_ptr)].  Per-step HIP-event times of an eager pass -> (rows, kinds)."""
     rows, kinds = [], {}
+    ABSORBED.clear()
     for bp, sp in bound:
         times = bp.profile(sp, reps=3)
         steps = [c[2] for c in bp.calls]             # includes the stand-alone uint8 normalisation launches, in order
+        ABSORBED.update(id(bp.calls[i][2]) for i in bp.noop_calls)
         for s, ms in zip(steps, times):
             n = bp.n
             rows.append((s, float(ms), n))
@@ -1060,7 +1065,7 @@ def main():
             out['cpu_baseline'] = cpu_baseline(full_model if full_model is not None else model, args.workload, args.blocks)
         if args.dump_steps:
             dump = [dict(kind=s.kind, name=s.name, kernel=kernel_name(s) if s.kind == 'conv' else s.kind,
-                         ms=ms, gflop=s.flops(n) / 1e9, mbytes=s.bytes(n) / 1e6,
+                         ms=ms, gflop=s.flops(n) / 1e9, mbytes=s.bytes(n) / 1e6, absorbed=id(s) in ABSORBED,
                          out=list(next(iter(s.outs.values())).shape) if s.outs else None) for s, ms, n in rows]
             with open(args.dump_steps, 'w') as f:
                 json.dump(dump, f, indent=1)

@@ -7,9 +7,26 @@
 // the spatial reduction runs over pixel-lanes: in-register partials -> wavefront __shfl_xor butterflies ->
 // one LDS hop across the workgroup's waves.
 #include "dh_kernels.h"
+#ifndef DH_DECODER_XCD_ORDER
+#define DH_DECODER_XCD_ORDER 1
+#endif
 
 namespace dh {
 namespace {
+
+// Work-group b runs on XCD b % 8.  The (frame, channel group) work-groups of ONE frame read the same cache lines (a pixel's
+// channels are contiguous: a group of 4-16 channels touches every 128-byte line of the frame's maps), so they belong on one
+// XCD's L2: each XCD gets a contiguous run of the (frame, group) order.  [r06: the per-launch PMC scan of the MPII forward
+// (profiles/r06_pmc_all_launches_mpii.json) showed the fused decoder fetching 4.0x its maps -- its four joint quads of a frame
+// sat on four XCDs.]  A pure re-mapping of work-groups: no result bit moves.
+__device__ __forceinline__ int xcd_order(int b, int nwg) {
+#if DH_DECODER_XCD_ORDER
+  const int xcd = b & 7, q = nwg >> 3, r = nwg & 7;
+  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
+#else
+  return b;
+#endif
+}
 
 constexpr int CG = 16;             // channels per workgroup (depth_from_maps; soft-argmax when there is enough work)
 constexpr int NTH = 256;           // threads per workgroup
@@ -50,8 +67,9 @@ __global__ __launch_bounds__(NTH) void softargmax2d_kernel(const SamArgs p) {
   const int cc = tid % CG, pl = tid / CG;
   const int wave = tid >> 6;
   const int groups = (p.C + CG - 1) / CG;
-  const int f = blockIdx.x / groups;
-  const int c0 = (blockIdx.x % groups) * CG;
+  const int wg = xcd_order((int)blockIdx.x, (int)gridDim.x);
+  const int f = wg / groups;
+  const int c0 = (wg % groups) * CG;
   const int c = c0 + cc;
   const bool cok = c < p.C;
   const int HW = p.H * p.W;
@@ -207,8 +225,9 @@ __global__ __launch_bounds__(NT) void softargmax2d_ctx_kernel(const SamArgs p, c
   const int cc = tid % CG, pl = tid / CG;
   const int wave = tid >> 6;
   const int groups = (J + 3) / 4;
-  const int f = blockIdx.x / groups;
-  const int j0 = (blockIdx.x % groups) * 4;
+  const int wg = xcd_order((int)blockIdx.x, (int)gridDim.x);
+  const int f = wg / groups;
+  const int j0 = (wg % groups) * 4;
   const int nch = 4 + 4 * nctx;
   const int HW = p.H * p.W;
   // channel of lane cc: joints j0 .. j0+3, then their contexts
@@ -374,8 +393,9 @@ __global__ __launch_bounds__(NTH) void depth_means_z_kernel(const float* __restr
   const int tid = threadIdx.x;
   const int cc = tid % CG, pl = tid / CG;
   const int groups = (DJ + CG - 1) / CG;
-  const int f = blockIdx.x / groups;
-  const int c = (blockIdx.x % groups) * CG + cc;
+  const int wg = xcd_order((int)blockIdx.x, (int)gridDim.x);
+  const int f = wg / groups;
+  const int c = (wg % groups) * CG + cc;
   float acc = 0.f;
   if (c < DJ) {
     const float* src = h + (size_t)f * HW * ldh + c;
@@ -482,8 +502,9 @@ __global__ __launch_bounds__(NTH) void depth_from_maps_kernel(const float* __res
   const int tid = threadIdx.x;
   const int cc = tid % CG, pl = tid / CG;
   const int groups = (J + CG - 1) / CG;
-  const int f = blockIdx.x / groups;
-  const int c = (blockIdx.x % groups) * CG + cc;
+  const int wg = xcd_order((int)blockIdx.x, (int)gridDim.x);
+  const int f = wg / groups;
+  const int c = (wg % groups) * CG + cc;
   float acc = 0.f;
   if (c < J) {
     const float* dp = d + (size_t)f * HW * ldd + c;
