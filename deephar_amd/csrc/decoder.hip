@@ -7,26 +7,15 @@
 // the spatial reduction runs over pixel-lanes: in-register partials -> wavefront __shfl_xor butterflies ->
 // one LDS hop across the workgroup's waves.
 #include "dh_kernels.h"
-#ifndef DH_DECODER_XCD_ORDER
-#define DH_DECODER_XCD_ORDER 1
-#endif
 
 namespace dh {
 namespace {
 
-// Work-group b runs on XCD b % 8.  The (frame, channel group) work-groups of ONE frame read the same cache lines (a pixel's
-// channels are contiguous: a group of 4-16 channels touches every 128-byte line of the frame's maps), so they belong on one
-// XCD's L2: each XCD gets a contiguous run of the (frame, group) order.  [r06: the per-launch PMC scan of the MPII forward
-// (profiles/r06_pmc_all_launches_mpii.json) showed the fused decoder fetching 4.0x its maps -- its four joint quads of a frame
-// sat on four XCDs.]  A pure re-mapping of work-groups: no result bit moves.
-__device__ __forceinline__ int xcd_order(int b, int nwg) {
-#if DH_DECODER_XCD_ORDER
-  const int xcd = b & 7, q = nwg >> 3, r = nwg & 7;
-  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
-#else
-  return b;
-#endif
-}
+// The (frame, channel group) work-groups of ONE frame read the same cache lines (a pixel's channels are contiguous: a group
+// of 4-16 channels touches every 128-byte line of the frame's maps), so they belong on one XCD's L2: the kernels below take
+// their pair from dh::xcd_order (dh_kernels.h).  [r06: the per-launch PMC scan of the MPII forward
+// (profiles/r06_pmc_all_launches.md) showed the fused decoder fetching 4.0x its maps -- its four joint quads of a frame sat on
+// four XCDs.]  A pure re-mapping of work-groups: no result bit moves.
 
 constexpr int CG = 16;             // channels per workgroup (depth_from_maps; soft-argmax when there is enough work)
 constexpr int NTH = 256;           // threads per workgroup

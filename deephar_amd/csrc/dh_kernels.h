@@ -14,6 +14,14 @@ using PoolArgs = dh_pool_args;
 using EltArgs = dh_elt_args;
 using SamArgs = dh_sam_args;
 
+// Work-group b runs on XCD b % 8 (eight XCDs, an L2 each).  -> the position of work-group b in an order that gives every XCD a
+// CONTIGUOUS run of [0, nwg): neighbours in that order -- the channel groups of one frame, the output rows of one image whose
+// pooling windows overlap -- share an L2 instead of each fetching the lines they have in common.  A bijection on [0, nwg).
+__device__ __forceinline__ int xcd_order(int b, int nwg) {
+  const int xcd = b & 7, q = nwg >> 3, r = nwg & 7;
+  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
+}
+
 int launch_conv_igemm(const ConvArgs& a, int cfg, hipStream_t s);
 int launch_normalize_u8(const unsigned char* x, const float* lut, float* y, long long n_pixels, int C, hipStream_t s);
 int conv_igemm_pick_cfg(int M, int Cout);

@@ -118,6 +118,9 @@ __global__ __launch_bounds__(256) void pool_kernel(const PoolArgs p) {
   constexpr int V = VEC ? 4 : 1;
   const int cn = p.C / V;
   const long long total = (long long)p.N * p.OH * p.OW * cn;
+  // (round 6 tried the XCD-contiguous block order here -- xcd_order, dh_kernels.h: overlapping windows of the 3 x 3 / stride-2
+  //  pooling then share an L2 and the fetched bytes drop from 1.54x to 1.17x the input, but the launch gets SLOWER: 430 -> 455 us
+  //  on SPNet-NTU's 128 x 128 x 96 pooling, 34 -> 42 us at 16 frames; profiles/r06_pmc_all_launches.md.  Round-robin order kept.)
   for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
        idx += (long long)gridDim.x * blockDim.x) {
     const int c = (int)(idx % cn) * V;
