@@ -569,7 +569,7 @@ __global__ __launch_bounds__(256) void kronecker_tiled_kernel(const float* __res
   constexpr int HP = JT + 4;                                       // LDS pitch of a pixel's heat-map values (floats)
   constexpr int JH = JT / 2;
   extern __shared__ __attribute__((aligned(16))) float4 kr_red[];  // [16 groups][JT / 2][16 quads], then the h chunk
-  float* hs = reinterpret_cast<float*>(kr_red + 16 * JH * 16);     // [64 pixels][HP]
+  float* hs = reinterpret_cast<float*>(kr_red + 16 * JH * 16);     // [2 buffers][64 pixels][HP]
   const int tid = threadIdx.x;
   const int q = tid & 15, g = tid >> 4;
   const int b = blockIdx.y;
@@ -583,25 +583,49 @@ __global__ __launch_bounds__(256) void kronecker_tiled_kernel(const float* __res
     float4 acc[JT];
 #pragma unroll
     for (int j = 0; j < JT; ++j) acc[j] = zero;
-    // chunks of 64 pixels = four per pixel group: their x rows are requested first, the chunk's heat-map values go
-    // through LDS meanwhile (coalesced load, zero-filled beyond jn / P), each thread then reads its pixels' JT values
-    // as float4 -- the same address for the 16 lanes of a group
-    for (int p0 = 0; p0 < P; p0 += 64) {
-      float4 xv[4];
+    // chunks of 64 pixels = four per pixel group.  [r06] Software-pipelined: the x rows and the heat-map values of chunk k + 1
+    // are requested before chunk k is multiplied (they wait in registers), the heat-map values go through a DOUBLE-buffered LDS
+    // tile (coalesced load, zero-filled beyond jn / P; each thread then reads its pixels' JT values as float4 -- the same
+    // address for the 16 lanes of a group) -- one barrier and no exposed memory round trip per chunk; at a couple of clips per
+    // call the loop used to be P / 64 serial round trips (33 us for the 32 x 32 level).  Same products, same order.
+    constexpr int HV = JT / 4;                                     // heat-map values a thread stages per chunk (64 * JT / 256)
+    auto load_x = [&](int p0, float4 (&xv)[4]) {
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
         const int p = p0 + g + 16 * u;
         xv[u] = *reinterpret_cast<const float4*>(xb + (size_t)(p < P ? p : P - 1) * ldx);
       }
-      __syncthreads();                                             // previous chunk's readers are done
-      for (int i = tid; i < 64 * JT; i += 256) {
+    };
+    auto load_h = [&](int p0, float (&hv)[HV]) {
+#pragma unroll
+      for (int k = 0; k < HV; ++k) {
+        const int i = tid + 256 * k;
         const int pp = i / JT, jj = i - pp * JT;
-        hs[pp * HP + jj] = (p0 + pp < P && jj < jn) ? hb[(size_t)(p0 + pp) * ldh + j0 + jj] : 0.f;
+        hv[k] = (p0 + pp < P && jj < jn) ? hb[(size_t)(p0 + pp) * ldh + j0 + jj] : 0.f;
+      }
+    };
+    float4 xv[4], xn[4];
+    float hc[HV], hn[HV];
+    load_x(0, xv);
+    load_h(0, hc);
+    __syncthreads();                                               // the previous joint tile's readers are done with both buffers
+    int buf = 0;
+    for (int p0 = 0; p0 < P; p0 += 64) {
+      float* hbuf = hs + buf * (64 * HP);
+#pragma unroll
+      for (int k = 0; k < HV; ++k) {
+        const int i = tid + 256 * k;
+        const int pp = i / JT, jj = i - pp * JT;
+        hbuf[pp * HP + jj] = hc[k];
+      }
+      if (p0 + 64 < P) {                                           // (uniform) next chunk's operands: in flight under this chunk
+        load_x(p0 + 64, xn);
+        load_h(p0 + 64, hn);
       }
       __syncthreads();
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
-        const float4* hrow = reinterpret_cast<const float4*>(hs + (g + 16 * u) * HP);
+        const float4* hrow = reinterpret_cast<const float4*>(hbuf + (g + 16 * u) * HP);
 #pragma unroll
         for (int j4 = 0; j4 < JT / 4; ++j4) {
           const float4 h = hrow[j4];
@@ -614,6 +638,11 @@ __global__ __launch_bounds__(256) void kronecker_tiled_kernel(const float* __res
           }
         }
       }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) xv[u] = xn[u];
+#pragma unroll
+      for (int k = 0; k < HV; ++k) hc[k] = hn[k];
+      buf ^= 1;
     }
     // sum over the 16 pixel groups, JT / 2 joints at a time
 #pragma unroll
@@ -778,9 +807,9 @@ int launch_kronecker(const float* hm, int ldh, const float* x, int ldx, float* f
     const dim3 grid((C + 63) / 64, B);
     const int fvec = ldf % 4 == 0 && al16(f);
     if (J <= 16 || (J > 20 && J % 20 != 0 && J % 16 == 0))
-      hipLaunchKernelGGL(kronecker_tiled_kernel<16>, grid, dim3(256), 16 * 8 * 16 * 16 + 64 * 20 * 4, s, hm, ldh, x, ldx, f, ldf, P, J, C, fvec);
+      hipLaunchKernelGGL(kronecker_tiled_kernel<16>, grid, dim3(256), 16 * 8 * 16 * 16 + 2 * 64 * 20 * 4, s, hm, ldh, x, ldx, f, ldf, P, J, C, fvec);
     else
-      hipLaunchKernelGGL(kronecker_tiled_kernel<20>, grid, dim3(256), 16 * 10 * 16 * 16 + 64 * 24 * 4, s, hm, ldh, x, ldx, f, ldf, P, J, C, fvec);
+      hipLaunchKernelGGL(kronecker_tiled_kernel<20>, grid, dim3(256), 16 * 10 * 16 * 16 + 2 * 64 * 24 * 4, s, hm, ldh, x, ldx, f, ldf, P, J, C, fvec);
     return check_launch();
   }
   hipLaunchKernelGGL(kronecker_kernel, dim3((C + 63) / 64, B), dim3(64), 0, s, hm, ldh, x, ldx, f, ldf, P, J, C);
