@@ -90,8 +90,19 @@ __device__ __forceinline__ void dwconv_lds_body(const DwArgs& p, const int tw, c
   float4* tile = dsm + KS * KS * DW_CQ;             // ring of th rows: [th][twh][DW_PITCH], + one dump cell
   const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
 
-  for (int i = tid; i < KS * KS * DW_CQ; i += NT)
-    wts[i] = ld4(p.w + (size_t)(i / DW_CQ) * p.C + c0 + (i % DW_CQ) * 4);
+  // [r06] Every load the work-group needs before its first FMA -- filter taps, prologue affine, the KS - 1 rows above the first
+  // band, the first band's rows -- is ISSUED before the first one is consumed: one memory round trip in front of the arithmetic
+  // instead of three (taps -> LDS, top rows -> LDS, band 0 -> LDS).  At a couple of clips per call a depthwise launch is a single
+  // band on a handful of CUs and those round trips were a third of its 9-13 us; at a throughput batch the other work-group of
+  // the CU covered them.  (Band k + 1 is still NOT requested under band k's arithmetic: see below.)
+  constexpr int WPT = (KS * KS * DW_CQ + NT - 1) / NT;
+  float4 wreg[WPT];
+#pragma unroll
+  for (int k = 0; k < WPT; ++k) {
+    const int i = tid + k * NT;
+    const int ic = i < KS * KS * DW_CQ ? i : 0;
+    wreg[k] = ld4(p.w + (size_t)(ic / DW_CQ) * p.C + c0 + (ic % DW_CQ) * 4);
+  }
   const int q = tid & (DW_CQ - 1);
   float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = zero;
   if constexpr (AFF) { sc = ld4(p.pre_scale + c0 + q * 4); sh = ld4(p.pre_shift + c0 + q * 4); }
@@ -116,26 +127,13 @@ __device__ __forceinline__ void dwconv_lds_body(const DwArgs& p, const int tw, c
     return (unsigned)iw < (unsigned)p.W ? ((((first_row + tr) >> ush) * w_in + (iw >> ush)) * p.ldx + c0 + q * 4) * 4 : DW_OOB;
   };
 
-  // ---- the KS - 1 rows above the first band (input rows -PT .. KS - 2 - PT) go to ring rows 0 .. KS - 2, once
-  {
-    float4 top[MAXT];
+  // ---- the KS - 1 rows above the first band (input rows -PT .. KS - 2 - PT) go to ring rows 0 .. KS - 2, once: requested here,
+  // written to the ring below (behind the first band's requests)
+  float4 top[MAXT];
 #pragma unroll
-    for (int j = 0; j < MAXT; ++j) {
-      const int px = (tid >> 3) + j * SP;
-      top[j] = buf_ld4(rs_x, px < (KS - 1) * twh ? px_offset(px, -p.PT) : DW_OOB);
-    }
-#pragma unroll
-    for (int j = 0; j < MAXT; ++j) {
-      const int px = (tid >> 3) + j * SP;
-      float4 v = top[j];
-      if constexpr (AFF) {
-        const int tr = row_of(px), iw = w0 - p.PL + px - tr * twh;
-        v = fma4(v, sc, sh);
-        if (!((unsigned)(tr - p.PT) < (unsigned)p.H && (unsigned)iw < (unsigned)p.W)) v = zero;
-      }
-      if constexpr (RELU) v = dw_relu4(v);
-      if (px < (KS - 1) * twh) tile[px * DW_PITCH + q] = v;
-    }
+  for (int j = 0; j < MAXT; ++j) {
+    const int px = (tid >> 3) + j * SP;
+    top[j] = buf_ld4(rs_x, px < (KS - 1) * twh ? px_offset(px, -p.PT) : DW_OOB);
   }
   // ---- every band then brings in only its `rows` NEW rows (window rows KS - 1 .. th - 1 = input rows r0 + KS - 1 - PT
   // ...): the KS - 1 rows it shares with the band above stay where they are.  Input row i lives in ring row (i + PT) % th.
@@ -162,6 +160,25 @@ __device__ __forceinline__ void dwconv_lds_body(const DwArgs& p, const int tw, c
 #pragma unroll
     for (int j = 0; j < MAXN; ++j) stage[j] = buf_ld4(rs_x, voff[j] + boff);
   };
+  fetch(0);
+  // ---- now the LDS side of the prologue: filter taps, then the top rows (prologue affine / ReLU / zero padding on the way in)
+#pragma unroll
+  for (int k = 0; k < WPT; ++k) {
+    const int i = tid + k * NT;
+    if (i < KS * KS * DW_CQ) wts[i] = wreg[k];
+  }
+#pragma unroll
+  for (int j = 0; j < MAXT; ++j) {
+    const int px = (tid >> 3) + j * SP;
+    float4 v = top[j];
+    if constexpr (AFF) {
+      const int tr = row_of(px), iw = w0 - p.PL + px - tr * twh;
+      v = fma4(v, sc, sh);
+      if (!((unsigned)(tr - p.PT) < (unsigned)p.H && (unsigned)iw < (unsigned)p.W)) v = zero;
+    }
+    if constexpr (RELU) v = dw_relu4(v);
+    if (px < (KS - 1) * twh) tile[px * DW_PITCH + q] = v;
+  }
   const int strips = tw >> 3;
   const int strip = (tid >> 3) % strips;
   const int row = (tid >> 3) / strips;
@@ -173,7 +190,7 @@ __device__ __forceinline__ void dwconv_lds_body(const DwArgs& p, const int tw, c
   for (int band = 0; band < bands; ++band) {
     const int r0 = band * rows;
     const int shift = ring0 * row_bytes;
-    fetch(band);
+    if (band > 0) fetch(band);
 #pragma unroll
     for (int j = 0; j < MAXN; ++j) {
       float4 v = stage[j];
