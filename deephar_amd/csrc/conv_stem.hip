@@ -42,14 +42,25 @@ __global__ __launch_bounds__(256, 2) void conv_stem_kernel(const ConvArgs p, con
   const int li = lane & 31, lh = lane >> 5;
 
   // ---- weights: standard packing, element (k, n) at ((k >> 2) * Np + n) * 4 + (k & 3), k = kh * KL + kl
-  for (int idx = tid; idx < KH * KLP * BN; idx += 256) {
+  // [r06] every weight load of the thread is in flight at once and lands in LDS behind the first halo request below: the
+  // straightforward loop (load, wait, ds_write, next) compiled to exactly that -- up to 39 DEPENDENT memory round trips at the
+  // start of every work-group (7 x 7: 9 856 weights / 256 threads).
+  constexpr int NWL = (KH * KLP * BN + 255) / 256;
+  float wst[NWL];
+#pragma unroll
+  for (int q = 0; q < NWL; ++q) {
+    const int idx = tid + q * 256;
     const int n = idx % BN, kk = idx / BN;
     const int kl = kk % KLP, kh = kk / KLP;
     const int k = kh * KL + kl;
-    Bs[idx] = (kl < KL && n < p.Cout) ? p.w[((size_t)(k >> 2) * p.Np + n) * 4 + (k & 3)] : 0.f;
+    const bool ok = idx < KH * KLP * BN && kl < KL && n < p.Cout;
+    const float v = p.w[ok ? ((size_t)(k >> 2) * p.Np + n) * 4 + (k & 3) : 0];
+    wst[q] = ok ? v : 0.f;
   }
+  float lst[U8 ? 3 : 1];
   if constexpr (U8) {
-    for (int i = tid; i < 3 * 256; i += 256) lut[i] = p.in_lut[i];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) lst[i] = p.in_lut[tid + i * 256];
   }
 
   const int pairs = p.OH >> 1;
@@ -96,6 +107,15 @@ __global__ __launch_bounds__(256, 2) void conv_stem_kernel(const ConvArgs p, con
     }
   };
   issue(0);
+#pragma unroll
+  for (int q = 0; q < NWL; ++q) {
+    const int idx = tid + q * 256;
+    if (idx < KH * KLP * BN) Bs[idx] = wst[q];
+  }
+  if constexpr (U8) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i) lut[tid + i * 256] = lst[i];
+  }
   __syncthreads();                                       // weights and table staged (the table is read by land())
 
   // ---- fragment addresses (float indices), fixed over the row pairs

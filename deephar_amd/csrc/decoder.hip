@@ -67,6 +67,8 @@ __global__ __launch_bounds__(NTH) void softargmax2d_kernel(const SamArgs p) {
   float* sgx = slab + HW * CG;
   float* sgy = sgx + p.W;
   if constexpr (STAGED) {
+    // (the coordinate grids' first values are requested BEFORE the maps and wait in registers: one round trip, not two)
+    const float gx0 = tid < p.W ? p.gx[tid] : 0.f, gy0 = tid < p.H ? p.gy[tid] : 0.f;
     const float* src = p.h + (size_t)f * HW * p.ldh + c0;
     const bool vec = (p.ldh % 4 == 0) && (c0 + CG <= p.C) && ((reinterpret_cast<uintptr_t>(src) & 15) == 0);
     if (vec) {
@@ -106,8 +108,10 @@ __global__ __launch_bounds__(NTH) void softargmax2d_kernel(const SamArgs p) {
       }
     }
     // the coordinate grids are read once per pixel in pass 2: keep them next to the maps
-    for (int i = tid; i < p.W; i += NTH) sgx[i] = p.gx[i];
-    for (int i = tid; i < p.H; i += NTH) sgy[i] = p.gy[i];
+    if (tid < p.W) sgx[tid] = gx0;
+    if (tid < p.H) sgy[tid] = gy0;
+    for (int i = tid + NTH; i < p.W; i += NTH) sgx[i] = p.gx[i];
+    for (int i = tid + NTH; i < p.H; i += NTH) sgy[i] = p.gy[i];
     __syncthreads();
   }
   auto at = [&](int px) -> float {
@@ -227,6 +231,7 @@ __global__ __launch_bounds__(NT) void softargmax2d_ctx_kernel(const SamArgs p, c
   float* sgx = slab + HW * CG;
   float* sgy = sgx + p.W;
   {
+    const float gx0 = tid < p.W ? p.gx[tid] : 0.f, gy0 = tid < p.H ? p.gy[tid] : 0.f;   // (requested before the maps, see above)
     const float* src = p.h + (size_t)f * HW * p.ldh;
     const int per = 1 + nctx;                           // float4 per pixel: the joints' quad, then nctx context quads
     const int total = HW * per;
@@ -249,8 +254,10 @@ __global__ __launch_bounds__(NT) void softargmax2d_ctx_kernel(const SamArgs p, c
         }
       }
     }
-    for (int i = tid; i < p.W; i += NT) sgx[i] = p.gx[i];
-    for (int i = tid; i < p.H; i += NT) sgy[i] = p.gy[i];
+    if (tid < p.W) sgx[tid] = gx0;
+    if (tid < p.H) sgy[tid] = gy0;
+    for (int i = tid + NT; i < p.W; i += NT) sgx[i] = p.gx[i];
+    for (int i = tid + NT; i < p.H; i += NT) sgy[i] = p.gy[i];
     __syncthreads();
   }
   auto at = [&](int px) -> float { return slab[px * CG + cc]; };
