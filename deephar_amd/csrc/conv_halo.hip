@@ -72,6 +72,7 @@ struct HaloGeom {
   int nbuf_a;       // 1 or 2 halo buffers
   int b_bytes;      // one weight stage, rounded up to whole 4 KB DMA passes
   int bpass;
+  int hc_magic;     // (1 << 20) / hc + 1: px / hc for px < 1024 as one multiply and a shift (an integer divide is ~40 VALU)
 };
 
 template <int KW, int TN, bool RELU>
@@ -116,7 +117,7 @@ __global__ __launch_bounds__(256, 2) void conv_halo_kernel(const ConvArgs p, con
   for (int j = 0; j < HMAXA; ++j) {
     const int slot = ((j * 4 + wave) << 6) + lane;
     const int px = slot / 5, sl = slot - px * 5;
-    const int r = px / g.hc, c = px - r * g.hc;
+    const int r = (int)(((unsigned)px * (unsigned)g.hc_magic) >> 20), c = px - r * g.hc;   // px / hc (px < 1024, hc <= 132: exact)
     const int ih = ih0 + r, iw = iw0 + c;
     const bool ok = sl < 4 && px < npix && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
     a_off[j] = ok ? ((unsigned)((n_img * p.H + ih) * p.W + iw) * p.ldx + sl * 4) * 4u : OOB;
@@ -254,6 +255,7 @@ bool geometry(const ConvArgs& a, int tn, HaloGeom* g) {
   g->a_bytes = (g->hr * g->hc * HPIX + 1023) & ~1023;
   g->b_bytes = (4 * a.KW * bn * 16 + 4095) & ~4095;
   g->bpass = g->b_bytes >> 12;
+  g->hc_magic = (1 << 20) / g->hc + 1;
   if ((g->a_bytes >> 10) > 4 * HMAXA || g->bpass > HMAXB) return false;
   // two work-groups per CU need <= 80 KB each; a second halo buffer (prefetch of the next chunk) when it fits
   const int epi = 4 * 32 * (bn + 4) * 4;
