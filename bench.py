@@ -807,6 +807,9 @@ def main():
                     help='mpii at N = 1: skip the compact h36m / ntu_spnet / speed2d legs appended to the line')
     ap.add_argument('--predict-frames', type=int, default=2048,
                     help='frames per Model.predict boundary measurement (SURVEY.md 8d: >= 2 000)')
+    ap.add_argument('--pre-predict', default=None,
+                    help="diagnostic: run Model.predict on host arrays of an MPII model first ('f32', 'u8', 'alloc': only allocate "
+                         "and free the host array) -- does it slow the device-resident step that follows?")
     args = ap.parse_args()
 
     if 'WORLD_SIZE' not in os.environ and args.gpus > 1:
@@ -827,6 +830,22 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs a HIP device (the product path has no CPU fallback)')
     torch.cuda.set_device(local_rank)
+    if args.pre_predict:
+        rng0 = np.random.default_rng(7)
+        if args.pre_predict == 'alloc':
+            x0 = np.tile(rng0.uniform(-1, 1, (256, 256, 256, 3)).astype(np.float32), (8, 1, 1, 1))
+            del x0
+        else:
+            m0 = build_mpii(8)
+            if args.pre_predict == 'u8':
+                x0 = np.tile(rng0.integers(0, 256, (256, 256, 256, 3), dtype=np.uint8), (8, 1, 1, 1))
+            else:
+                x0 = np.tile(rng0.uniform(-1, 1, (256, 256, 256, 3)).astype(np.float32), (8, 1, 1, 1))
+            m0.predict(x0, batch_size=64)
+            m0.predict(x0, batch_size=64)
+            del m0, x0
+        import gc
+        gc.collect()
     if world > 1 or args.force_collective:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         if world == 1:

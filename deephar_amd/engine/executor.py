@@ -783,6 +783,36 @@ _GRAPH_GRAVEYARD = []
 # plans (the default, Model.num_streams = 1) destroy their graphs and are not counted.
 _MULTISTREAM_GRAPHS = 0
 MAX_MULTISTREAM_GRAPHS = max(0, int(os.environ.get('DEEPHAR_MAX_MULTISTREAM_GRAPHS', '64')))
+# ---- the package's HIP streams, one per ROLE and device ----------------------------------------------------------------
+# ROCm maps every HIP stream onto one of GPU_MAX_HW_QUEUES (default 4) hardware queues when it is created.  Until round 6 every
+# Model owned a compute stream, every predict() a copy stream, every frame-sharded clip model a collective stream: the fourth
+# or fifth stream of a process landed on a hardware queue another one already used, and two streams that order each other with
+# events through ONE hardware queue cost the frame-sharded SPNet / merge models 4.7 % of their step (22.0 -> 23.0 ms, 7.85 ->
+# 8.24 ms) -- in any process that had called Model.predict on another model before (profiles/r06_hw_queue_collision.md).
+# Now: ONE stream per role -- 'compute' (every Model's launches; models of a process run one after the other anyway), 'copy'
+# (predict's host-device staging), 'head' (the head stage of a frame-sharded clip model), 'comm' (its collective) -- four
+# streams, four hardware queues, whatever the process did before.
+_ROLE_STREAMS = {}
+
+
+def shared_stream(device, role):
+    torch = _torch()
+    device = torch.device(device)
+    key = (device.index if device.index is not None else torch.cuda.current_device(), role)
+    st = _ROLE_STREAMS.get(key)
+    if st is None:
+        with torch.cuda.device(device):
+            for r in ('compute', 'copy', 'head', 'comm'):           # a fixed creation order: the mapping does not depend on
+                k = (key[0], r)                                      # which role a process happens to need first
+                if k not in _ROLE_STREAMS:
+                    _ROLE_STREAMS[k] = torch.cuda.Stream(device=device)
+        st = _ROLE_STREAMS.get(key)
+        if st is None:
+            with torch.cuda.device(device):
+                st = _ROLE_STREAMS[key] = torch.cuda.Stream(device=device)
+    return st
+
+
 _STAGING_THREADS = max(1, min(8, (os.cpu_count() or 2) // 2, int(os.environ.get('DEEPHAR_STAGING_THREADS', '6'))))
 _POOL = None
 
@@ -797,7 +827,7 @@ def _staging_pool():
 
 
 class Executor:
-    def __init__(self, plan, device=None, use_graph=True, autotune=True):
+    def __init__(self, plan, device=None, use_graph=True, autotune=True, stream_role='compute'):
         torch = _torch()
         if not torch.cuda.is_available():
             raise _lib.DeepharHipError('no HIP device visible: deephar_amd runs only on an AMD GPU (gfx950); '
@@ -812,8 +842,7 @@ class Executor:
         self.bound = {}            # key -> BoundPlan, most recently used last; at most `max_bound` are kept
         self.max_bound = max(1, int(os.environ.get('DEEPHAR_MAX_BOUND_PLANS', '4')))
         self._wstamp = None        # sum of Param.version over plan.params at the last refresh / first bind
-        with torch.cuda.device(self.device):
-            self.stream = torch.cuda.Stream(device=self.device)
+        self.stream = shared_stream(self.device, stream_role)
 
     @property
     def stream_ptr(self):
@@ -969,7 +998,7 @@ class Executor:
             if self._wstamp is None:
                 self._wstamp = self._weight_stamp()
             if getattr(self, 'copy_stream', None) is None:
-                self.copy_stream = torch.cuda.Stream(device=self.device)
+                self.copy_stream = shared_stream(self.device, 'copy')
             want = torch.uint8 if bp.u8 is not None else torch.float32
             slot_bytes = sum(bs * int(np.prod(v.shape)) for v in self.plan.inputs) * (1 if want == torch.uint8 else 4)
             depth = max(2, min(nchunks, int(os.environ.get('DEEPHAR_PREDICT_DEPTH', '8')),

@@ -219,7 +219,7 @@ class Model:
     def executor(self):
         if self._exec is None:
             from .engine.executor import Executor
-            self._exec = Executor(self.plan)
+            self._exec = Executor(self.plan, stream_role=getattr(self, '_stream_role', 'compute'))
         return self._exec
 
     def predict(self, x, batch_size=32, verbose=0):

@@ -211,6 +211,8 @@ class ShardedClipModel:
             if stage is not None:
                 stage.num_streams, stage.gemm_precision = model.num_streams, model.gemm_precision
                 stage.stream_policy = model.stream_policy
+        if self.head_model is not None:
+            self.head_model._stream_role = 'head'                  # (its executor is created on first use: engine/executor.py shared_stream)
         self.frame_fn = frame_fn or self._frame_hip
         self.head_fn = head_fn or self._head_hip
         self.last_outputs = None
@@ -254,7 +256,8 @@ class ShardedClipModel:
         F = fx.stream
         cur = torch.cuda.current_stream()
         if self._comm_stream is None:
-            self._comm_stream = torch.cuda.Stream(device=fx.device)
+            from .engine.executor import shared_stream
+            self._comm_stream = shared_stream(fx.device, 'comm')
         K = self._comm_stream
         slot = self._slots[self._step % 2]
         self._step += 1
