@@ -423,14 +423,22 @@ class BoundPlan:
             raise NotImplementedError('no binding for step kind %r' % k)
 
     # ---- execution -----------------------------------------------------------------------------------------
-    def _side_streams(self):
-        """Lazily created extra HIP streams + sync events for the parallel branches of the plan."""
+    def _side_streams(self, main_ptr=None):
+        """The extra HIP streams + sync events for the parallel branches of the plan.  [r06] The streams are the engine's
+        role streams other than the one this plan is launched on (shared_stream below: every stream the package creates costs one
+        of ROCm's four hardware queues, and a side stream that shares a queue with its plan's main stream is slow); only a plan
+        with more branches than those creates streams of its own."""
         if getattr(self, '_streams', None) is None:
             lib = self.lib
             self._streams, self._events, self._join, self._fork, self._relay = [], {}, [], C.c_void_p(), {}
-            for _ in range(self.plan.nstreams - 1):
+            roles = [shared_stream(self.device, r) for r in ('head', 'comm', 'copy')]
+            spare = [st for st in roles if main_ptr is None or st.cuda_stream != main_ptr]
+            for k in range(self.plan.nstreams - 1):
                 st, ev = C.c_void_p(), C.c_void_p()
-                _lib.check(lib.dh_stream_create(C.byref(st)), 'stream create')
+                if k < len(spare):
+                    st = C.c_void_p(spare[k].cuda_stream)
+                else:
+                    _lib.check(lib.dh_stream_create(C.byref(st)), 'stream create')
                 _lib.check(lib.dh_event_create_sync(C.byref(ev)), 'event create')
                 self._streams.append(st)
                 self._join.append(ev)
@@ -455,7 +463,7 @@ class BoundPlan:
                 if rc != 0:
                     _lib.check(rc, 'step %s (%s)' % (step.kind, step.name))
             return
-        side = self._side_streams()
+        side = self._side_streams(stream_ptr)
         ptrs = [stream_ptr] + [st for st in side]
         for fn, args, step in self.calls[:self.npre]:          # input staging runs before the fork
             _lib.check(fn(*args, stream_ptr), step.kind)
