@@ -801,6 +801,19 @@ MAX_MULTISTREAM_GRAPHS = max(0, int(os.environ.get('DEEPHAR_MAX_MULTISTREAM_GRAP
 # (predict's host-device staging), 'head' (the head stage of a frame-sharded clip model), 'comm' (its collective) -- four
 # streams, four hardware queues, whatever the process did before.
 _ROLE_STREAMS = {}
+_ROLE_LOCKS = {}        # (device index, role) -> RLock: the models of a process share a stream, so ONE thread at a time enqueues on it
+                        # (a hipGraph capture on the stream would otherwise swallow another thread's launches)
+
+
+def stream_lock(device, role):
+    import threading
+    torch = _torch()
+    device = torch.device(device)
+    key = (device.index if device.index is not None else torch.cuda.current_device(), role)
+    lk = _ROLE_LOCKS.get(key)
+    if lk is None:
+        lk = _ROLE_LOCKS.setdefault(key, threading.RLock())
+    return lk
 
 
 def shared_stream(device, role):
@@ -851,12 +864,17 @@ class Executor:
         self.max_bound = max(1, int(os.environ.get('DEEPHAR_MAX_BOUND_PLANS', '4')))
         self._wstamp = None        # sum of Param.version over plan.params at the last refresh / first bind
         self.stream = shared_stream(self.device, stream_role)
+        self._lock = stream_lock(self.device, stream_role)
 
     @property
     def stream_ptr(self):
         return self.stream.cuda_stream
 
     def bind(self, n, u8_norm=None):
+        with self._lock:          # one thread at a time on the shared stream (engine/executor.py: stream_lock)
+            return self._bind_locked(n, u8_norm)
+
+    def _bind_locked(self, n, u8_norm=None):
         """u8_norm: None for float inputs; a channel_power (1 or a per-channel list) when the inputs are raw uint8
         frames to be normalised on the GPU like utils/transform.normalize_channels."""
         key = n if u8_norm is None else (n, repr(u8_norm))
@@ -935,6 +953,10 @@ class Executor:
             dst[:m].copy_(src.to(self.device, non_blocking=True).to(torch.float32))
 
     def forward(self, bp):
+        with self._lock:          # one thread at a time on the shared stream (engine/executor.py: stream_lock)
+            return self._forward_locked(bp)
+
+    def _forward_locked(self, bp):
         """Enqueue one forward pass of the bound plan on the executor stream."""
         if self.use_graph and (bp.graph is not None or bp.capture(self.stream_ptr)):
             bp.replay(self.stream_ptr)
@@ -980,6 +1002,10 @@ class Executor:
         return outs
 
     def run_pipelined(self, arrays, bs, u8_norm=None, verbose=0):
+        with self._lock:          # one thread at a time on the shared stream (engine/executor.py: stream_lock)
+            return self._run_pipelined_locked(arrays, bs, u8_norm, verbose)
+
+    def _run_pipelined_locked(self, arrays, bs, u8_norm=None, verbose=0):
         """Forward over all rows of `arrays` (host arrays, equal leading dim) in chunks of `bs`, as a 3-stage pipeline:
              host   : cast / copy chunk i+2 into pinned staging on a small THREAD POOL (row slices in parallel; the
                       copy releases the GIL) while the main thread enqueues chunk i -- a float32 batch of 64 frames is
@@ -1091,6 +1117,10 @@ class Executor:
                 for k in range(nres)]
 
     def run_device(self, tensors, n=None, inputs_copied=None):
+        with self._lock:          # one thread at a time on the shared stream (engine/executor.py: stream_lock)
+            return self._run_device_locked(tensors, n, inputs_copied)
+
+    def _run_device_locked(self, tensors, n=None, inputs_copied=None):
         """Device tensors in ([m <= n, ...] float32 on this device), device VIEWS of the outputs out (valid until the
         next forward of the same bound plan); everything is enqueued on `self.stream`, nothing touches the host.
         An input may be any strided view with the input's element count whose leading dim is m -- e.g. the

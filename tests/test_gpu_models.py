@@ -357,6 +357,47 @@ def test_pool_read_by_segmented_conv_is_bit_identical(hip_lib, cuda, monkeypatch
                     assert np.array_equal(a, b), (frames, layout, streams)
 
 
+def test_two_models_predict_from_two_threads(hip_lib, cuda):
+    """[r06] Every Model of a process launches on ONE compute stream (engine/executor.py: shared_stream -- a stream per Model
+    ran into ROCm's four hardware queues, profiles/r06_hw_queue_collision.md); a lock per stream keeps one thread's hipGraph
+    capture from swallowing another thread's launches.  Two different models, bound, tuned, captured and run from two threads
+    at the same time -- a 2-D ReceptionNet through predict on host arrays, a two-stream SPNet on clips: the bits of the same
+    calls made one after the other."""
+    import threading
+    rng = np.random.default_rng(61)
+    x = rng.uniform(-1, 1, (12, 256, 256, 3)).astype(np.float32)
+    clips = rng.uniform(-1, 1, (4, 8, 128, 128, 3)).astype(np.float32)
+
+    def rec():
+        m, _ = _build(2, 2, 16, num_context_per_joint=2)
+        return m
+
+    def sp():
+        m, _, _, _ = _spnet(8, 'pa16j2d', 15, 2, [1, 2], 160, replica=True, res=128)
+        m.num_streams, m.stream_policy = 2, 'tail'
+        return m
+    want_a = rec().predict(x, batch_size=4)
+    want_b = sp().predict(clips, batch_size=2)
+    ma, mb = rec(), sp()                                  # fresh models: binding, tuning and capture happen inside the threads
+    got, errs = {}, []
+
+    def run(tag, m, arr, bs):
+        try:
+            for _ in range(3):
+                got[tag] = m.predict(arr, batch_size=bs)
+        except Exception as e:                            # noqa: BLE001  (reported below, with the thread's tag)
+            errs.append((tag, repr(e)))
+    ta = threading.Thread(target=run, args=('a', ma, x, 4))
+    tb = threading.Thread(target=run, args=('b', mb, clips, 2))
+    ta.start(); tb.start(); ta.join(); tb.join()
+    assert not errs, errs
+    assert ma.executor.stream is mb.executor.stream       # the point of the test: they DO share the stream
+    for w, g in zip(want_a, got['a']):
+        assert np.array_equal(w, g)
+    for w, g in zip(want_b, got['b']):
+        assert np.array_equal(w, g)
+
+
 def test_pose_times_confidence_folded_into_the_read_out(hip_lib, cuda, monkeypatch):
     """[r06] multiply([p, c]) in front of an action head (spnet.py:108) on a replica read-out whose coordinates and confidence
     have no other reader is folded into the soft-argmax launch (dh_sam_args.xy_times_conf): one launch less per head, the same
